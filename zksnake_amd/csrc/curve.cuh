@@ -1,0 +1,182 @@
+// curve.cuh -- short-Weierstrass (a = 0) group arithmetic for G1 (over Fp) and G2 (over Fp2) of
+// BN254 and BLS12-381, generic over the field facade F (FpOps / Fp2Ops from field.cuh).
+//
+// Replaces what the reference gets from ark-ec 0.4.2 `short_weierstrass::{Affine, Projective}`
+// behind PointG1/PointG2 (src/bn254/curve.rs:19-324, src/bls12_381/curve.rs twins) and inside
+// VariableBaseMSM (src/bn254/curve.rs:356-392).  ark stores Jacobian coordinates; the MSM
+// buckets here use extended-Jacobian XYZZ coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2) because
+// the mixed addition costs 8M + 2S with no field inversion -- every result is converted to
+// the unique affine representative before it leaves the library, so outputs are
+// representation-independent and bit-exact against any correct implementation.
+#pragma once
+#include "field.cuh"
+
+namespace zkmi {
+
+template <class F>
+struct Affine {
+    typename F::T x, y;  // (0, 0) encodes the point at infinity (never on a curve with b != 0)
+};
+
+template <class F>
+struct XYZZ {
+    typename F::T X, Y, ZZ, ZZZ;  // ZZ == 0 <=> infinity
+};
+
+template <class F>
+ZK_HD bool aff_is_inf(const Affine<F>& p) {
+    return F::is_zero(p.x) && F::is_zero(p.y);
+}
+
+template <class F>
+ZK_HD Affine<F> aff_neg(const Affine<F>& p) {
+    return {p.x, F::neg(p.y)};
+}
+
+template <class F>
+ZK_HD XYZZ<F> xyzz_inf() {
+    return {F::zero(), F::zero(), F::zero(), F::zero()};
+}
+
+template <class F>
+ZK_HD bool xyzz_is_inf(const XYZZ<F>& p) {
+    return F::is_zero(p.ZZ);
+}
+
+template <class F>
+ZK_HD XYZZ<F> xyzz_from_affine(const Affine<F>& p) {
+    if (aff_is_inf<F>(p)) return xyzz_inf<F>();
+    return {p.x, p.y, F::one(), F::one()};
+}
+
+template <class F>
+ZK_HD XYZZ<F> xyzz_neg(const XYZZ<F>& p) {
+    return {p.X, F::neg(p.Y), p.ZZ, p.ZZZ};
+}
+
+// 2*P for an affine P (mdbl-2008-s-1 with a = 0)
+template <class F>
+ZK_HD XYZZ<F> xyzz_dbl_affine(const Affine<F>& p) {
+    typedef typename F::T T;
+    if (aff_is_inf<F>(p) || F::is_zero(p.y)) return xyzz_inf<F>();
+    T U = F::dbl(p.y);
+    T V = F::sqr(U);
+    T W = F::mul(U, V);
+    T S = F::mul(p.x, V);
+    T xx = F::sqr(p.x);
+    T M = F::add(F::dbl(xx), xx);
+    T X3 = F::sub(F::sqr(M), F::dbl(S));
+    T Y3 = F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.y));
+    return {X3, Y3, V, W};
+}
+
+// 2*P (dbl-2008-s-1, a = 0)
+template <class F>
+ZK_HD XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
+    typedef typename F::T T;
+    if (xyzz_is_inf<F>(p) || F::is_zero(p.Y)) return xyzz_inf<F>();
+    T U = F::dbl(p.Y);
+    T V = F::sqr(U);
+    T W = F::mul(U, V);
+    T S = F::mul(p.X, V);
+    T xx = F::sqr(p.X);
+    T M = F::add(F::dbl(xx), xx);
+    T X3 = F::sub(F::sqr(M), F::dbl(S));
+    T Y3 = F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.Y));
+    T ZZ3 = F::mul(V, p.ZZ);
+    T ZZZ3 = F::mul(W, p.ZZZ);
+    return {X3, Y3, ZZ3, ZZZ3};
+}
+
+// acc + q, q affine (madd-2008-s): 8M + 2S.  Handles infinity, doubling and cancellation.
+template <class F>
+ZK_HD void xyzz_add_affine(XYZZ<F>& acc, const Affine<F>& q) {
+    typedef typename F::T T;
+    if (aff_is_inf<F>(q)) return;
+    if (xyzz_is_inf<F>(acc)) {
+        acc = {q.x, q.y, F::one(), F::one()};
+        return;
+    }
+    T U2 = F::mul(q.x, acc.ZZ);
+    T S2 = F::mul(q.y, acc.ZZZ);
+    T Pd = F::sub(U2, acc.X);
+    T R = F::sub(S2, acc.Y);
+    if (F::is_zero(Pd)) {
+        if (F::is_zero(R)) acc = xyzz_dbl_affine<F>(q);
+        else acc = xyzz_inf<F>();
+        return;
+    }
+    T PP = F::sqr(Pd);
+    T PPP = F::mul(Pd, PP);
+    T Q = F::mul(acc.X, PP);
+    T X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+    T Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(acc.Y, PPP));
+    acc.X = X3;
+    acc.Y = Y3;
+    acc.ZZ = F::mul(acc.ZZ, PP);
+    acc.ZZZ = F::mul(acc.ZZZ, PPP);
+}
+
+// acc + q, both XYZZ (add-2008-s): 12M + 2S
+template <class F>
+ZK_HD XYZZ<F> xyzz_add(const XYZZ<F>& p, const XYZZ<F>& q) {
+    typedef typename F::T T;
+    if (xyzz_is_inf<F>(q)) return p;
+    if (xyzz_is_inf<F>(p)) return q;
+    T U1 = F::mul(p.X, q.ZZ);
+    T U2 = F::mul(q.X, p.ZZ);
+    T S1 = F::mul(p.Y, q.ZZZ);
+    T S2 = F::mul(q.Y, p.ZZZ);
+    T Pd = F::sub(U2, U1);
+    T R = F::sub(S2, S1);
+    if (F::is_zero(Pd)) {
+        if (F::is_zero(R)) return xyzz_dbl<F>(p);
+        return xyzz_inf<F>();
+    }
+    T PP = F::sqr(Pd);
+    T PPP = F::mul(Pd, PP);
+    T Q = F::mul(U1, PP);
+    T X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+    T Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(S1, PPP));
+    T ZZ3 = F::mul(F::mul(p.ZZ, q.ZZ), PP);
+    T ZZZ3 = F::mul(F::mul(p.ZZZ, q.ZZZ), PPP);
+    return {X3, Y3, ZZ3, ZZZ3};
+}
+
+// unique affine representative: x = X/ZZ, y = Y/ZZZ  (one inversion: 1/ZZZ, then 1/ZZ = ZZZ^-2 * ZZ^2 ...
+// simpler: invert ZZ*ZZZ once)
+template <class F>
+ZK_HD Affine<F> xyzz_to_affine(const XYZZ<F>& p) {
+    typedef typename F::T T;
+    if (xyzz_is_inf<F>(p)) return {F::zero(), F::zero()};
+    T inv = F::inv(F::mul(p.ZZ, p.ZZZ));  // 1/(ZZ*ZZZ)
+    T izz = F::mul(inv, p.ZZZ);           // 1/ZZ
+    T izzz = F::mul(inv, p.ZZ);           // 1/ZZZ
+    return {F::mul(p.X, izz), F::mul(p.Y, izzz)};
+}
+
+// k*P by left-to-right double-and-add; k canonical little-endian 32-bit limbs (already < r)
+template <class F>
+ZK_HD XYZZ<F> xyzz_scalar_mul(const Affine<F>& p, const uint32_t* k, int nlimbs) {
+    XYZZ<F> acc = xyzz_inf<F>();
+    bool started = false;
+    for (int i = nlimbs * 32 - 1; i >= 0; --i) {
+        if (started) acc = xyzz_dbl<F>(acc);
+        if ((k[i >> 5] >> (i & 31)) & 1) {
+            xyzz_add_affine<F>(acc, p);
+            started = true;
+        }
+    }
+    return acc;
+}
+
+// y^2 == x^3 + b
+template <class F>
+ZK_HD bool aff_on_curve(const Affine<F>& p, const typename F::T& b) {
+    if (aff_is_inf<F>(p)) return true;
+    typename F::T lhs = F::sqr(p.y);
+    typename F::T rhs = F::add(F::mul(F::sqr(p.x), p.x), b);
+    return F::eq(lhs, rhs);
+}
+
+}  // namespace zkmi
