@@ -1,0 +1,143 @@
+/*
+ * zkmi.h -- C ABI of libzkmi.so, the MI355X (gfx950) proving backend that replaces the
+ * field/curve hot path of Merricx/zksnake behind Groth16.prove()/Plonk.prove().
+ *
+ * Drop-in boundary: the reference crosses from Python into Rust through the pyo3 module
+ * `zksnake._algebra` (reference src/lib.rs:6-185).  Each entry point below names the pyo3
+ * function(s) it stands in for (file:line under the reference tree).  INTEGRATION.md shows the
+ * ctypes stub a maintainer would add to python/zksnake/{ecc,polynomial}.py.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; no C++/torch types; never throws; returns an int status;
+ *     zk_last_error() gives the message of the last failure on the calling thread.
+ *   - field elements: canonical (non-Montgomery) integers as little-endian 64-bit limbs.
+ *       Fr (both curves): 4 limbs.  Fq: 4 limbs (BN254) / 6 limbs (BLS12-381).
+ *     Values >= modulus are reduced on entry, like `Fr::from(BigUint)` in the reference
+ *     (src/bn254/polynomial.rs:538, src/bn254/curve.rs:359).
+ *   - points: affine (x, y); G1 = 2 Fq elements, G2 = 4 (x.c0, x.c1, y.c0, y.c1); the point at
+ *     infinity is the all-zero encoding ((0,0) is on none of the four curves since b != 0).
+ *   - "host" functions take host memory and copy; "_dev" functions take HIP device pointers
+ *     (e.g. torch tensor data_ptr()) plus a hipStream_t passed as void* (NULL = default stream).
+ *   - the caller owns every buffer it passes; handles are freed explicitly.
+ *   - calls may come from several threads (ctypes releases the GIL): the library serialises GPU
+ *     work per handle internally.
+ */
+#ifndef ZKMI_H
+#define ZKMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZK_CURVE_BN254 0
+#define ZK_CURVE_BLS12_381 1
+#define ZK_G1 1
+#define ZK_G2 2
+
+#define ZK_OK 0
+#define ZK_ERR_LENGTH 1        /* "Number of points and scalars mismatch" (src/bn254/curve.rs:369-371) */
+#define ZK_ERR_DOMAIN 2        /* domain larger than 2^two-adicity (polynomial.rs:48 unwrap / :638 error) */
+#define ZK_ERR_HIP 3           /* HIP / RCCL runtime failure, or no GPU present */
+#define ZK_ERR_POINT 4         /* bad point encoding / not on curve (curve.rs:137-140) */
+#define ZK_ERR_ARG 5           /* invalid curve/group/size argument */
+#define ZK_ERR_NOT_DIVISIBLE 6 /* (U*V - W) mod Z != 0 (groth16/qap.py:67-69) */
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+
+int zk_init(int device);            /* select the HIP device for this process; ZK_ERR_HIP when no GPU */
+int zk_shutdown(void);              /* free cached twiddle tables and workspaces */
+int zk_device_count(void);          /* number of visible HIP devices (0 without a GPU; never fails) */
+const char* zk_last_error(void);
+const char* zk_version(void);
+
+/* limb counts, so bindings do not hard-code them */
+int zk_fq_limbs(int curve);         /* 64-bit limbs per base-field element: 4 / 6 */
+int zk_point_limbs(int curve, int group); /* 64-bit limbs per affine point */
+
+/* ---- scalar-field vectors (polynomial_bn254 / polynomial_bls12_381 submodules) ---------- */
+
+/* fft / ifft / coset_fft / coset_ifft (src/bn254/polynomial.rs:535-585).
+ * `in` holds n_in elements; the domain is next_pow2(size); the input is zero-padded (or, when
+ * longer than the domain, folded modulo X^N - 1 as ark-poly does); `out` receives the whole
+ * domain in natural order. coset != 0 uses the reference's offset (= the domain generator). */
+int zk_ntt(int curve, int inverse, int coset, uint64_t n_in, const uint64_t* in, uint64_t size, uint64_t* out);
+
+/* mul_over_evaluation_domain / add_over_evaluation_domain (polynomial.rs:587-634): element-wise
+ * over `size` entries; entries beyond n_a / n_b count as zero.  op: 0 = mul, 1 = add, 2 = sub. */
+int zk_vec_op(int curve, int op, uint64_t size, uint64_t n_a, const uint64_t* a, uint64_t n_b, const uint64_t* b,
+              uint64_t* out);
+
+/* Polynomial.divide_by_vanishing_poly (polynomial.rs:466-489): coeffs (len) = q*(X^n - 1) + rem.
+ * q must hold max(len - n, 0) elements, rem min(len, n). *rem_is_zero tells whether rem == 0. */
+int zk_poly_div_vanishing(int curve, uint64_t n, uint64_t len, const uint64_t* coeffs, uint64_t* q, uint64_t* rem,
+                          int* rem_is_zero);
+
+/* Device-resident forms: in place on a vector of 2^log_n canonical Fr elements. */
+int zk_ntt_dev(int curve, int inverse, int log_n, void* d_data, void* stream);
+int zk_vec_op_dev(int curve, int op, uint64_t n, const void* d_a, const void* d_b, void* d_out, void* stream);
+
+/* Fused QAP.evaluate_witness tail (python/zksnake/groth16/qap.py:57-69): from the evaluation vectors
+ * a = A.w, b = B.w, c = C.w (2^log_n canonical Fr elements each, device memory) compute in place the
+ * coefficient vectors u = iNTT(a), v = iNTT(b) and write h (2^log_n elements, h[2^log_n - 1] = 0) with
+ * u*v - w = h*(X^n - 1).  Everything stays in HBM: 3 iNTT(n) + 2 NTT(2n) + mul + iNTT(2n) + fold.
+ * d_work must hold 4 * 2^log_n elements.  *divisible (host int) is set to 0 when the remainder is
+ * non-zero (the reference raises ValueError there). */
+int zk_qap_h_dev(int curve, int log_n, void* d_a_u, void* d_b_v, const void* d_c, void* d_h, void* d_work,
+                 int* divisible, void* stream);
+
+/* ---- curve groups (ec_bn254 / ec_bls12_381 submodules) ---------------------------------- */
+
+/* multiscalar_mul_g1 / multiscalar_mul_g2 (src/bn254/curve.rs:356-392, bls12_381 :366-402):
+ * out = sum_i scalars[i] * bases[i].  n_scalars != n_points -> ZK_ERR_LENGTH. */
+int zk_msm(int curve, int group, uint64_t n_points, uint64_t n_scalars, const uint64_t* scalars,
+           const uint64_t* bases, uint64_t* out);
+
+/* batch_multi_scalar_g1 / _g2 (src/bn254/curve.rs:326-354): out[i] = scalars[i] * bases[i];
+ * broadcast != 0 means `bases` holds one point used for every scalar (ecc.py:93-94). */
+int zk_batch_mul(int curve, int group, uint64_t n, const uint64_t* scalars, const uint64_t* bases, int broadcast,
+                 uint64_t* out);
+
+/* Device-resident bases ("proving key stays in HBM").  zk_msm_plan_create uploads/normalises the
+ * bases once (host or device pointer per `bases_on_device`) and sizes the workspace for up to n
+ * points.  flags: bit0 = precompute the per-window multiples 2^(c*w) * P_i so that every window
+ * shares one bucket set (uses n * windows * point bytes of HBM); window_bits 0 = automatic. */
+#define ZK_MSM_PRECOMPUTE 1
+int zk_msm_plan_create(int curve, int group, uint64_t n, const void* bases, int bases_on_device, int flags,
+                       int window_bits, uint64_t* handle);
+int zk_msm_plan_destroy(uint64_t handle);
+/* scalars: n_scalars <= plan n canonical Fr elements (host or device per `scalars_on_device`); the
+ * first n_scalars bases are used (ecc.py:118-119 truncation rule).  Result: one affine point in host
+ * memory.  window_first/window_count select a window range for multi-GPU sharding (count 0 = all):
+ * the partial result then is sum over those windows of 2^(c*w) * W_w, so partials of disjoint ranges
+ * add up to the full MSM. */
+int zk_msm_plan_run(uint64_t handle, uint64_t n_scalars, const void* scalars, int scalars_on_device,
+                    int window_first, int window_count, uint64_t* out, void* stream);
+int zk_msm_plan_windows(uint64_t handle, int* window_bits, int* n_windows);
+/* milliseconds of the stages of the last zk_msm_plan_run on this plan, measured with HIP events on
+ * the launch stream: [0] digits+sort, [1] bucket accumulation (dominant kernel), [2] bucket reduction,
+ * [3] host tail, [4] total.  Returns the number of floats written. */
+int zk_msm_plan_timings(uint64_t handle, float* ms, int cap);
+
+/* ---- single-point host arithmetic (PointG1 / PointG2 methods, src/bn254/curve.rs:25-324) -- */
+
+int zk_point_add(int curve, int group, const uint64_t* a, const uint64_t* b, uint64_t* out);      /* __add__ */
+int zk_point_neg(int curve, int group, const uint64_t* a, uint64_t* out);                          /* __neg__ */
+int zk_point_mul(int curve, int group, const uint64_t* a, const uint64_t* scalar, uint64_t* out);  /* __mul__ */
+int zk_point_on_curve(int curve, int group, const uint64_t* a);                                    /* 1 / 0 */
+int zk_point_generator(int curve, int group, uint64_t* out);                                       /* g1() / g2() */
+/* to_bytes / from_bytes = ark-serialize compressed (curve.rs:127-146): 32/64 B (BN254), 48/96 B (BLS12-381) */
+int zk_point_compress(int curve, int group, const uint64_t* a, uint8_t* out);
+int zk_point_decompress(int curve, int group, const uint8_t* in, uint64_t* out);
+int zk_point_bytes(int curve, int group);
+
+/* ---- scalar-field host helpers (setup/verify side; polynomial.rs:518-533,636-652) -------- */
+
+int zk_fr_root_of_unity(int curve, uint64_t n, uint64_t* out);                 /* get_evaluation_point(n, 1) */
+int zk_fr_lagrange_coeffs(int curve, uint64_t n, const uint64_t* tau, uint64_t* out); /* evaluate_lagrange_coefficients */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKMI_H */

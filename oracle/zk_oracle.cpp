@@ -367,21 +367,27 @@ static int ark_window(size_t n) {
     return lg_ceil * 69 / 100 + 2;
 }
 
+// Window count: ark uses ceil(num_bits / w) and folds the last carry back into the top digit; when
+// w divides num_bits (BLS12-381 Fr is 255 bits: w = 3, 5, 15, 17) that top digit can exceed the
+// 2^(w-1) buckets, so this restatement always keeps one spare bit: floor(num_bits / w) + 1
+// windows (identical to ark's count whenever w does not divide num_bits), final carry == 0.
+static int window_count(int num_bits, int w) { return num_bits / w + 1; }
+
 static void make_digits(const uint64_t* a, int w, int num_bits, std::vector<int64_t>& out, size_t off, size_t stride) {
     const uint64_t radix = 1ULL << w;
     const uint64_t mask = radix - 1;
     uint64_t carry = 0;
-    int count = (num_bits + w - 1) / w;
+    int count = window_count(num_bits, w);
     for (int i = 0; i < count; ++i) {
         int bit_offset = i * w;
         int u = bit_offset / 64, b = bit_offset % 64;
         uint64_t bits;
-        if (b < 64 - w || u == 3) bits = a[u] >> b;
+        if (u > 3) bits = 0;
+        else if (b < 64 - w || u == 3) bits = a[u] >> b;
         else bits = (a[u] >> b) | (a[u + 1] << (64 - b));
         uint64_t coef = carry + (bits & mask);
         carry = (coef + radix / 2) >> w;
         int64_t d = (int64_t)coef - (int64_t)(carry << w);
-        if (i == count - 1) d += (int64_t)(carry << w);
         out[off + (size_t)i * stride] = d;
     }
 }
@@ -391,7 +397,7 @@ static Jac<K> pippenger(size_t n, const uint64_t* scalars, const uint64_t* bases
     if (n == 0) return Jac<K>::infinity();
     const int num_bits = FrTag::ctx().bits;
     const int c = c_override > 0 ? c_override : ark_window(n);
-    const int nwin = (num_bits + c - 1) / c;
+    const int nwin = window_count(num_bits, c);
     std::vector<Aff<K>> pts(n);
     for (size_t i = 0; i < n; ++i) pts[i] = load_aff<K>(bases + i * 2 * K::WORDS);
     std::vector<int64_t> digits((size_t)nwin * n);

@@ -1,0 +1,169 @@
+"""
+ctypes binding of libzkmi.so (the C ABI declared in include/zkmi.h).
+
+This is the only place the Python host touches native code.  There is no CPU fallback:
+when the library is missing `load()` raises, and when no GPU is visible every compute entry
+point fails with ZkError (status ZK_ERR_HIP).
+"""
+
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkmi.so")
+
+ZK_OK = 0
+ZK_ERR_LENGTH = 1
+ZK_ERR_DOMAIN = 2
+ZK_ERR_HIP = 3
+ZK_ERR_POINT = 4
+ZK_ERR_ARG = 5
+ZK_ERR_NOT_DIVISIBLE = 6
+
+CURVE_BN254 = 0
+CURVE_BLS12_381 = 1
+G1 = 1
+G2 = 2
+
+MSM_PRECOMPUTE = 1
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_u64 = ctypes.c_uint64
+
+# every symbol include/zkmi.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "zk_init": (_i, [_i]),
+    "zk_shutdown": (_i, []),
+    "zk_device_count": (_i, []),
+    "zk_last_error": (ctypes.c_char_p, []),
+    "zk_version": (ctypes.c_char_p, []),
+    "zk_fq_limbs": (_i, [_i]),
+    "zk_point_limbs": (_i, [_i, _i]),
+    "zk_ntt": (_i, [_i, _i, _i, _u64, _u64p, _u64, _u64p]),
+    "zk_vec_op": (_i, [_i, _i, _u64, _u64, _u64p, _u64, _u64p, _u64p]),
+    "zk_poly_div_vanishing": (_i, [_i, _u64, _u64, _u64p, _u64p, _u64p, ctypes.POINTER(_i)]),
+    "zk_ntt_dev": (_i, [_i, _i, _i, _vp, _vp]),
+    "zk_vec_op_dev": (_i, [_i, _i, _u64, _vp, _vp, _vp, _vp]),
+    "zk_qap_h_dev": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_i), _vp]),
+    "zk_msm": (_i, [_i, _i, _u64, _u64, _u64p, _u64p, _u64p]),
+    "zk_batch_mul": (_i, [_i, _i, _u64, _u64p, _u64p, _i, _u64p]),
+    "zk_msm_plan_create": (_i, [_i, _i, _u64, _vp, _i, _i, _i, _u64p]),
+    "zk_msm_plan_destroy": (_i, [_u64]),
+    "zk_msm_plan_run": (_i, [_u64, _u64, _vp, _i, _i, _i, _u64p, _vp]),
+    "zk_msm_plan_windows": (_i, [_u64, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "zk_msm_plan_timings": (_i, [_u64, ctypes.POINTER(ctypes.c_float), _i]),
+    "zk_point_add": (_i, [_i, _i, _u64p, _u64p, _u64p]),
+    "zk_point_neg": (_i, [_i, _i, _u64p, _u64p]),
+    "zk_point_mul": (_i, [_i, _i, _u64p, _u64p, _u64p]),
+    "zk_point_on_curve": (_i, [_i, _i, _u64p]),
+    "zk_point_generator": (_i, [_i, _i, _u64p]),
+    "zk_point_compress": (_i, [_i, _i, _u64p, _u8p]),
+    "zk_point_decompress": (_i, [_i, _i, _u8p, _u64p]),
+    "zk_point_bytes": (_i, [_i, _i]),
+    "zk_fr_root_of_unity": (_i, [_i, _u64, _u64p]),
+    "zk_fr_lagrange_coeffs": (_i, [_i, _u64, _u64p, _u64p]),
+}
+
+
+class ZkError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"libzkmi status {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+_lib = None
+_lock = threading.Lock()
+_initialised = False
+
+
+def load():
+    """dlopen libzkmi.so and attach prototypes; raises if the library has not been built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "or `make -C zksnake_amd/csrc` (there is no CPU fallback)"
+                )
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(status):
+    if status != ZK_OK:
+        msg = load().zk_last_error().decode("utf-8", "replace")
+        raise ZkError(status, msg)
+
+
+def ensure_gpu(device=None):
+    """select the HIP device once per process; raises ZkError(ZK_ERR_HIP) when there is no GPU."""
+    global _initialised
+    lib = load()
+    if not _initialised or device is not None:
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, lib.zk_device_count())
+        check(lib.zk_init(device))
+        _initialised = True
+    return lib
+
+
+def u64p(arr):
+    return arr.ctypes.data_as(_u64p)
+
+
+def u8p(arr):
+    return arr.ctypes.data_as(_u8p)
+
+
+def curve_id(name):
+    try:
+        return {"BN254": 0, "BN128": 0, "ALT_BN128": 0, "BLS12_381": 1}[name]
+    except KeyError:
+        raise KeyError(name) from None
+
+
+def fq_limbs(cid):
+    return 4 if cid == 0 else 6
+
+
+def point_limbs(cid, group):
+    return 2 * fq_limbs(cid) * group
+
+
+# ---- int <-> limb marshalling (the reference marshals Python ints through pyo3 BigUint) ----
+
+def ints_to_limbs(vals, words=4, modulus=None):
+    """list of non-negative ints -> (n, words) uint64, little-endian limbs.  Negative ints raise
+    OverflowError, as pyo3's BigUint extraction does in the reference; with `modulus` values are
+    reduced first, which is what `Fr::from(BigUint)` does (src/bn254/curve.rs:359)."""
+    nbytes = 8 * words
+    chunks = []
+    for v in vals:
+        v = int(v)
+        if v < 0:
+            raise OverflowError("can't convert negative int to unsigned")
+        if modulus is not None and v >= modulus:
+            v %= modulus
+        chunks.append(v.to_bytes(nbytes, "little"))
+    return np.frombuffer(b"".join(chunks), dtype=np.uint64).reshape(len(vals), words).copy()
+
+
+def limbs_to_ints(arr):
+    arr = np.ascontiguousarray(arr, dtype=np.uint64)
+    words = arr.shape[-1]
+    raw = arr.tobytes()
+    step = 8 * words
+    return [int.from_bytes(raw[i:i + step], "little") for i in range(0, len(raw), step)]

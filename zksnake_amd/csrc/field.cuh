@@ -14,11 +14,18 @@
 #include "field_params.h"
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define ZK_HD __host__ __device__ __forceinline__
 #define ZK_D __device__ __forceinline__
+#if defined(ZK_NOINLINE_MUL)
+#define ZK_MUL __host__ __device__ __attribute__((noinline))
+#else
+#define ZK_MUL ZK_HD
+#endif
 #else
 #define ZK_HD inline
 #define ZK_D inline
+#define ZK_MUL inline
 #endif
 
 namespace zkmi {
@@ -156,7 +163,7 @@ ZK_HD Fp<P> fp_dbl(const Fp<P>& a) {
 // Finely-integrated operand scanning: for each limb of b one pass adds a*b_i and m*p
 // together, so the accumulator never needs more than N+1 limbs.
 template <class P>
-ZK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
+ZK_MUL Fp<P> fp_mul(const Fp<P> a, const Fp<P> b) {
     constexpr int N = P::N;
     uint32_t t[N + 1];
 #pragma unroll

@@ -1,0 +1,400 @@
+// host.hip -- the host-side part of libzkmi: lifecycle, single-point arithmetic, the
+// compressed point codecs and a few scalar-field helpers used by setup/verify.
+//
+// These stand in for the PointG1/PointG2 pyclass methods of the reference
+// (src/bn254/curve.rs:25-186,194-324 and the bls12_381 twin): __add__/__neg__/__mul__,
+// to_bytes/from_bytes (ark-serialize 0.4.2 compressed encodings),
+// g1()/g2(), and for get_evaluation_point / evaluate_lagrange_coefficients
+// (src/bn254/polynomial.rs:518-533,645-652).  The reference runs all of these on the CPU as
+// well: they touch one point (or O(n) scalars at setup time), not the proving hot path.
+#include <vector>
+#include "common.cuh"
+#include "curve_consts.h"
+
+extern "C" void zk_ntt_free_cache(void);
+extern "C" void zk_msm_free_all(void);
+
+namespace zkmi {
+
+template <class G> struct CurveConsts;
+template <> struct CurveConsts<Bn254G1> { static const uint32_t* gen() { return Bn254Consts::G1_GEN; } static const uint32_t* b() { return Bn254Consts::G1_B; } };
+template <> struct CurveConsts<Bn254G2> { static const uint32_t* gen() { return Bn254Consts::G2_GEN; } static const uint32_t* b() { return Bn254Consts::G2_B; } };
+template <> struct CurveConsts<Bls381G1> { static const uint32_t* gen() { return Bls381Consts::G1_GEN; } static const uint32_t* b() { return Bls381Consts::G1_B; } };
+template <> struct CurveConsts<Bls381G2> { static const uint32_t* gen() { return Bls381Consts::G2_GEN; } static const uint32_t* b() { return Bls381Consts::G2_B; } };
+
+template <class G>
+static Affine<typename G::F> load_point(const uint64_t* src) {
+    typedef typename G::F F;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(src);
+    Affine<F> p;
+    p.x = F::from_canonical(w);
+    p.y = F::from_canonical(w + F::LIMBS);
+    return p;
+}
+
+template <class G>
+static void store_point(uint64_t* dst, const Affine<typename G::F>& p) {
+    typedef typename G::F F;
+    uint32_t* w = reinterpret_cast<uint32_t*>(dst);
+    F::to_canonical(w, p.x);
+    F::to_canonical(w + F::LIMBS, p.y);
+}
+
+template <class G>
+static bool point_on_curve(const Affine<typename G::F>& p) {
+    typedef typename G::F F;
+    typename F::T b = F::from_canonical(CurveConsts<G>::b());
+    return aff_on_curve<F>(p, b);
+}
+
+template <class FrP>
+static void reduce_scalar(uint32_t* k, const uint64_t* scalar) {
+    memcpy(k, scalar, FrP::N * 4);
+    for (int r = 0; r < 10; ++r) {
+        uint32_t t[FrP::N];
+        if (fp_sub_mod_raw<FrP>(t, k)) break;
+        memcpy(k, t, sizeof(t));
+    }
+}
+
+// ---- square roots (both base fields have p = 3 mod 4) ---------------------------------------------
+
+template <class P>
+static bool fp_sqrt(const Fp<P>& a, Fp<P>* out) {
+    Fp<P> s = fp_pow<P>(a, P::SQRT_E, P::N);
+    if (!fp_eq<P>(fp_sqr<P>(s), a)) return false;
+    *out = s;
+    return true;
+}
+
+template <class P>
+static bool fp2_sqrt(const Fp2<P>& a, Fp2<P>* out) {
+    if (fp2_is_zero<P>(a)) { *out = a; return true; }
+    Fp<P> s;
+    if (fp_is_zero<P>(a.c1)) {
+        if (fp_sqrt<P>(a.c0, &s)) { *out = {s, fp_zero<P>()}; return true; }
+        if (fp_sqrt<P>(fp_neg<P>(a.c0), &s)) { *out = {fp_zero<P>(), s}; return true; }
+        return false;
+    }
+    Fp<P> norm = fp_add<P>(fp_sqr<P>(a.c0), fp_sqr<P>(a.c1));
+    Fp<P> alpha;
+    if (!fp_sqrt<P>(norm, &alpha)) return false;
+    Fp<P> two = fp_dbl<P>(fp_one<P>());
+    Fp<P> inv2 = fp_inv<P>(two);
+    Fp<P> delta = fp_mul<P>(fp_add<P>(a.c0, alpha), inv2);
+    Fp<P> x0;
+    if (!fp_sqrt<P>(delta, &x0)) {
+        delta = fp_mul<P>(fp_sub<P>(a.c0, alpha), inv2);
+        if (!fp_sqrt<P>(delta, &x0)) return false;
+    }
+    Fp<P> x1 = fp_mul<P>(a.c1, fp_inv<P>(fp_dbl<P>(x0)));
+    Fp2<P> cand = {x0, x1};
+    if (!fp2_eq<P>(fp2_sqr<P>(cand), a)) return false;
+    *out = cand;
+    return true;
+}
+
+template <class P> static bool coord_sqrt(const Fp<P>& a, Fp<P>* o) { return fp_sqrt<P>(a, o); }
+template <class P> static bool coord_sqrt(const Fp2<P>& a, Fp2<P>* o) { return fp2_sqrt<P>(a, o); }
+
+// "y is the lexicographically larger of {y, -y}" (ark: y > -y; Fp2 compares c1 first, then c0)
+template <class P>
+static bool coord_is_larger(const Fp<P>& y) {
+    uint32_t c[P::N];
+    fp_to_canonical<P>(c, y);
+    return fp_canonical_gt_half<P>(c);
+}
+template <class P>
+static bool coord_is_larger(const Fp2<P>& y) {
+    if (!fp_is_zero<P>(y.c1)) return coord_is_larger<P>(y.c1);
+    return coord_is_larger<P>(y.c0);
+}
+
+// ---- compressed encodings ---------------------------------------------------------------------------
+
+static void words_to_bytes(uint8_t* dst, const uint32_t* w, int nbytes, bool big_endian) {
+    for (int i = 0; i < nbytes; ++i) {
+        uint8_t b = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+        dst[big_endian ? nbytes - 1 - i : i] = b;
+    }
+}
+static void bytes_to_words(uint32_t* w, int nwords, const uint8_t* src, int nbytes, bool big_endian) {
+    for (int i = 0; i < nwords; ++i) w[i] = 0;
+    for (int i = 0; i < nbytes; ++i) {
+        uint8_t b = src[big_endian ? nbytes - 1 - i : i];
+        w[i >> 2] |= (uint32_t)b << (8 * (i & 3));
+    }
+}
+template <class P>
+static bool canonical_lt_mod(const uint32_t* c) {
+    uint32_t t[P::N];
+    return fp_sub_mod_raw<P>(t, c) != 0;
+}
+
+template <class G>
+static int compress_impl(const uint64_t* a, uint8_t* out) {
+    typedef typename G::F F;
+    typedef typename F::Params P;
+    constexpr bool bls = G::CURVE == ZK_CURVE_BLS12_381;
+    constexpr int fb = bls ? 48 : 32;            // bytes per base-field element
+    constexpr int comps = F::LIMBS / P::N;       // 1 (G1) or 2 (G2)
+    constexpr int total = fb * comps;
+    Affine<F> p = load_point<G>(a);
+    memset(out, 0, total);
+    if (aff_is_inf<F>(p)) {
+        if (bls) out[0] = 0xC0; else out[total - 1] = 0x40;
+        return ZK_OK;
+    }
+    if (!point_on_curve<G>(p)) return fail(ZK_ERR_POINT, "point is not on the curve");
+    const uint32_t* xw = reinterpret_cast<const uint32_t*>(a);
+    bool larger = coord_is_larger(p.y);
+    if (bls) {
+        // zcash: big-endian, c1 first for Fp2; bit7 compressed, bit6 infinity, bit5 y-largest
+        for (int k = 0; k < comps; ++k) words_to_bytes(out + k * fb, xw + (comps - 1 - k) * P::N, fb, true);
+        out[0] |= 0x80;
+        if (larger) out[0] |= 0x20;
+    } else {
+        // ark-serialize: little-endian, c0 first; flags in the top bits of the last byte
+        for (int k = 0; k < comps; ++k) words_to_bytes(out + k * fb, xw + k * P::N, fb, false);
+        if (larger) out[total - 1] |= 0x80;
+    }
+    return ZK_OK;
+}
+
+template <class G>
+static int decompress_impl(const uint8_t* in, uint64_t* out) {
+    typedef typename G::F F;
+    typedef typename F::Params P;
+    typedef typename G::Fr FrP;
+    constexpr bool bls = G::CURVE == ZK_CURVE_BLS12_381;
+    constexpr int fb = bls ? 48 : 32;
+    constexpr int comps = F::LIMBS / P::N;
+    constexpr int total = fb * comps;
+    uint8_t buf[total];
+    memcpy(buf, in, total);
+    bool inf, larger;
+    if (bls) {
+        uint8_t flags = buf[0] & 0xE0;
+        buf[0] &= 0x1F;
+        if (!(flags & 0x80)) return fail(ZK_ERR_POINT, "Cannot deserialize point: uncompressed encoding");
+        inf = flags & 0x40;
+        larger = flags & 0x20;
+    } else {
+        uint8_t flags = buf[total - 1] & 0xC0;
+        buf[total - 1] &= 0x3F;
+        if (flags == 0xC0) return fail(ZK_ERR_POINT, "Cannot deserialize point: invalid flags");
+        inf = flags & 0x40;
+        larger = flags & 0x80;
+    }
+    uint32_t xw[F::LIMBS];
+    for (int k = 0; k < comps; ++k) {
+        if (bls) bytes_to_words(xw + (comps - 1 - k) * P::N, P::N, buf + k * fb, fb, true);
+        else bytes_to_words(xw + k * P::N, P::N, buf + k * fb, fb, false);
+    }
+    if (inf) {
+        for (int i = 0; i < F::LIMBS; ++i)
+            if (xw[i]) return fail(ZK_ERR_POINT, "Cannot deserialize point: non-zero x with the infinity flag");
+        if (larger) return fail(ZK_ERR_POINT, "Cannot deserialize point: invalid flags");
+        memset(out, 0, (size_t)2 * F::LIMBS * 4);
+        return ZK_OK;
+    }
+    for (int k = 0; k < comps; ++k)
+        if (!canonical_lt_mod<P>(xw + k * P::N)) return fail(ZK_ERR_POINT, "Cannot deserialize point: x is not a field element");
+    typename F::T x = F::from_canonical(xw);
+    typename F::T rhs = F::add(F::mul(F::sqr(x), x), F::from_canonical(CurveConsts<G>::b()));
+    typename F::T y;
+    if (!coord_sqrt(rhs, &y)) return fail(ZK_ERR_POINT, "Cannot deserialize point: x is not on the curve");
+    if (coord_is_larger(y) != larger) y = F::neg(y);
+    Affine<F> p = {x, y};
+    // subgroup check (ark's deserialize_compressed validates): r * P == infinity
+    uint32_t r[FrP::N];
+    memcpy(r, FrP::MOD, sizeof(r));
+    if (!xyzz_is_inf<F>(xyzz_scalar_mul<F>(p, r, FrP::N))) return fail(ZK_ERR_POINT, "Cannot deserialize point: not in the prime-order subgroup");
+    store_point<G>(out, p);
+    return ZK_OK;
+}
+
+// ---- scalar-field helpers ---------------------------------------------------------------------------
+
+template <class P>
+static Fp<P> fr_root(uint64_t n) {
+    int log_n = log2_u64(n);
+    Fp<P> w = fp_const<P>(P::ROOT);
+    for (int k = 0; k < P::TWO_ADICITY - log_n; ++k) w = fp_sqr<P>(w);
+    return w;
+}
+
+template <class P>
+static int lagrange_impl(uint64_t n_in, const uint64_t* tau_c, uint64_t* out) {
+    uint64_t n = next_pow2_u64(n_in == 0 ? 1 : n_in);
+    int log_n = log2_u64(n);
+    if (log_n > P::TWO_ADICITY) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
+    Fp<P> tau = fp_from_canonical<P>(reinterpret_cast<const uint32_t*>(tau_c));
+    Fp<P> w = fr_root<P>(n);
+    Fp<P> tn = tau;
+    for (int k = 0; k < log_n; ++k) tn = fp_sqr<P>(tn);
+    Fp<P> z = fp_sub<P>(tn, fp_one<P>());
+    uint32_t* o = reinterpret_cast<uint32_t*>(out);
+    if (fp_is_zero<P>(z)) {
+        Fp<P> cur = fp_one<P>();
+        for (uint64_t i = 0; i < n; ++i) {
+            Fp<P> v = fp_eq<P>(cur, tau) ? fp_one<P>() : fp_zero<P>();
+            fp_to_canonical<P>(o + i * P::N, v);
+            cur = fp_mul<P>(cur, w);
+        }
+        return ZK_OK;
+    }
+    uint32_t nn[P::N] = {0};
+    nn[0] = (uint32_t)n;
+    if (P::N > 1) nn[1] = (uint32_t)(n >> 32);
+    Fp<P> zn = fp_mul<P>(z, fp_inv<P>(fp_from_canonical<P>(nn)));
+    // L_i = zn * w^i / (tau - w^i): batch-invert the denominators
+    std::vector<Fp<P>> den(n), pre(n), wi(n);
+    Fp<P> cur = fp_one<P>(), run = fp_one<P>();
+    for (uint64_t i = 0; i < n; ++i) {
+        wi[i] = cur;
+        den[i] = fp_sub<P>(tau, cur);
+        pre[i] = run;
+        run = fp_mul<P>(run, den[i]);
+        cur = fp_mul<P>(cur, w);
+    }
+    Fp<P> inv = fp_inv<P>(run);
+    for (uint64_t i = n; i-- > 0;) {
+        Fp<P> di = fp_mul<P>(inv, pre[i]);
+        inv = fp_mul<P>(inv, den[i]);
+        Fp<P> l = fp_mul<P>(fp_mul<P>(zn, wi[i]), di);
+        fp_to_canonical<P>(o + i * P::N, l);
+    }
+    return ZK_OK;
+}
+
+static int g_device = -1;
+
+}  // namespace zkmi
+
+using namespace zkmi;
+
+extern "C" {
+
+int zk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int zk_init(int device) {
+    int n = zk_device_count();
+    if (n <= 0) return fail(ZK_ERR_HIP, "no HIP device visible: libzkmi has no CPU fallback");
+    if (device < 0 || device >= n) return fail(ZK_ERR_ARG, "device index out of range");
+    ZK_HIP(hipSetDevice(device));
+    g_device = device;
+    return ZK_OK;
+}
+
+int zk_shutdown(void) {
+    zk_msm_free_all();
+    zk_ntt_free_cache();
+    return ZK_OK;
+}
+
+const char* zk_last_error(void) { return last_error_ref().c_str(); }
+const char* zk_version(void) { return "zkmi 0.1 (gfx950)"; }
+
+int zk_fq_limbs(int curve) { return curve == ZK_CURVE_BN254 ? 4 : (curve == ZK_CURVE_BLS12_381 ? 6 : -1); }
+int zk_point_limbs(int curve, int group) {
+    int f = zk_fq_limbs(curve);
+    if (f < 0 || (group != ZK_G1 && group != ZK_G2)) return -1;
+    return 2 * f * group;
+}
+int zk_point_bytes(int curve, int group) {
+    if (group != ZK_G1 && group != ZK_G2) return -1;
+    if (curve == ZK_CURVE_BN254) return 32 * group;
+    if (curve == ZK_CURVE_BLS12_381) return 48 * group;
+    return -1;
+}
+
+int zk_point_add(int curve, int group, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+#define CALL(G)                                                              \
+    {                                                                        \
+        typedef G::F F;                                                      \
+        XYZZ<F> acc = xyzz_from_affine<F>(load_point<G>(a));                 \
+        xyzz_add_affine<F>(acc, load_point<G>(b));                           \
+        store_point<G>(out, xyzz_to_affine<F>(acc));                         \
+        return ZK_OK;                                                        \
+    }
+    ZK_DISPATCH_GROUP(curve, group, CALL);
+#undef CALL
+}
+
+int zk_point_neg(int curve, int group, const uint64_t* a, uint64_t* out) {
+#define CALL(G)                                                              \
+    {                                                                        \
+        typedef G::F F;                                                      \
+        store_point<G>(out, aff_neg<F>(load_point<G>(a)));                   \
+        return ZK_OK;                                                        \
+    }
+    ZK_DISPATCH_GROUP(curve, group, CALL);
+#undef CALL
+}
+
+int zk_point_mul(int curve, int group, const uint64_t* a, const uint64_t* scalar, uint64_t* out) {
+#define CALL(G)                                                              \
+    {                                                                        \
+        typedef G::F F;                                                      \
+        uint32_t k[G::Fr::N];                                                \
+        reduce_scalar<G::Fr>(k, scalar);                                     \
+        XYZZ<F> r = xyzz_scalar_mul<F>(load_point<G>(a), k, G::Fr::N);       \
+        store_point<G>(out, xyzz_to_affine<F>(r));                           \
+        return ZK_OK;                                                        \
+    }
+    ZK_DISPATCH_GROUP(curve, group, CALL);
+#undef CALL
+}
+
+int zk_point_on_curve(int curve, int group, const uint64_t* a) {
+#define CALL(G) return point_on_curve<G>(load_point<G>(a)) ? 1 : 0
+    ZK_DISPATCH_GROUP(curve, group, CALL);
+#undef CALL
+}
+
+int zk_point_generator(int curve, int group, uint64_t* out) {
+#define CALL(G)                                                                          \
+    {                                                                                    \
+        memcpy(out, CurveConsts<G>::gen(), (size_t)2 * G::F::LIMBS * 4);                 \
+        return ZK_OK;                                                                    \
+    }
+    ZK_DISPATCH_GROUP(curve, group, CALL);
+#undef CALL
+}
+
+int zk_point_compress(int curve, int group, const uint64_t* a, uint8_t* out) {
+#define CALL(G) return compress_impl<G>(a, out)
+    ZK_DISPATCH_GROUP(curve, group, CALL);
+#undef CALL
+}
+
+int zk_point_decompress(int curve, int group, const uint8_t* in, uint64_t* out) {
+#define CALL(G) return decompress_impl<G>(in, out)
+    ZK_DISPATCH_GROUP(curve, group, CALL);
+#undef CALL
+}
+
+int zk_fr_root_of_unity(int curve, uint64_t n, uint64_t* out) {
+#define CALL(P)                                                                          \
+    {                                                                                    \
+        uint64_t m = next_pow2_u64(n == 0 ? 1 : n);                                      \
+        if (log2_u64(m) > P::TWO_ADICITY) return fail(ZK_ERR_DOMAIN, "Domain size is too large"); \
+        fp_to_canonical<P>(reinterpret_cast<uint32_t*>(out), fr_root<P>(m));             \
+        return ZK_OK;                                                                    \
+    }
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_fr_lagrange_coeffs(int curve, uint64_t n, const uint64_t* tau, uint64_t* out) {
+#define CALL(P) return lagrange_impl<P>(n, tau, out)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+}  // extern "C"
