@@ -52,6 +52,15 @@ int zk_device_count(void);          /* number of visible HIP devices (0 without 
 const char* zk_last_error(void);
 const char* zk_version(void);
 
+/* raw device memory for bindings that do not bring their own allocator (hipMalloc/hipFree/hipMemcpy);
+ * a torch tensor's data_ptr() is equally valid wherever a device pointer is expected. */
+int zk_dev_alloc(uint64_t bytes, void** d_ptr);
+int zk_dev_free(void* d_ptr);
+int zk_dev_upload(void* d_dst, const void* h_src, uint64_t bytes);
+int zk_dev_download(void* h_dst, const void* d_src, uint64_t bytes);
+int zk_dev_memset(void* d_dst, int value, uint64_t bytes);
+int zk_dev_synchronize(void);
+
 /* limb counts, so bindings do not hard-code them */
 int zk_fq_limbs(int curve);         /* 64-bit limbs per base-field element: 4 / 6 */
 int zk_point_limbs(int curve, int group); /* 64-bit limbs per affine point */
@@ -77,6 +86,12 @@ int zk_poly_div_vanishing(int curve, uint64_t n, uint64_t len, const uint64_t* c
 /* Device-resident forms: in place on a vector of 2^log_n canonical Fr elements. */
 int zk_ntt_dev(int curve, int inverse, int log_n, void* d_data, void* stream);
 int zk_vec_op_dev(int curve, int op, uint64_t n, const void* d_a, const void* d_b, void* d_out, void* stream);
+
+/* SparseArray.dot (python/zksnake/array.py:36-44) as a CSR sparse matrix-vector product over Fr:
+ * out[row] = sum_k vals[k] * w[cols[k]] for k in [row_ptr[row], row_ptr[row+1]).  vals / w / out are
+ * canonical Fr vectors in device memory; row_ptr (n_rows+1) and cols are uint32 device arrays. */
+int zk_spmv_dev(int curve, uint64_t n_rows, const void* d_row_ptr, const void* d_cols, const void* d_vals,
+                const void* d_w, void* d_out, void* stream);
 
 /* Fused QAP.evaluate_witness tail (python/zksnake/groth16/qap.py:57-69): from the evaluation vectors
  * a = A.w, b = B.w, c = C.w (2^log_n canonical Fr elements each, device memory) compute in place the

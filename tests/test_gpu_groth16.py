@@ -1,0 +1,149 @@
+"""GPU parity for the whole proving path through the Python host that mirrors the reference's API:
+proof bytes with pinned toxic waste / blinding equal the closed-form proof of the oracle, proofs verify,
+forged inputs fail, byte layouts round-trip (the reference's own test style, tests/test_groth16.py:68-208)."""
+
+import numpy as np
+import pytest
+
+from oracle import pyref
+from zksnake_amd import _native as N
+from zksnake_amd import workloads as W
+from zksnake_amd.arithmetization import R1CS
+from zksnake_amd.ecc import EllipticCurve
+from zksnake_amd.groth16 import Groth16, Proof, ProvingKey, VerifyingKey
+
+pytestmark = pytest.mark.gpu
+
+TOXIC = (0x1234567, 0x2345678, 0x3456789, 0x456789A, 0x56789AB)
+BLIND = (0x6789ABC, 0x789ABCD)
+
+
+def _r1cs(trip, curve):
+    A, B, C, n_row, n_col, n_pub, w = trip
+    unz = lambda m: tuple(list(t) for t in zip(*m))  # noqa: E731
+    return R1CS.from_triplets(unz(A), unz(B), unz(C), n_row, n_col, n_pub, curve), w, n_pub
+
+
+def _oracle_proof_bytes(trip, cv):
+    A, B, C, n_row, n_col, n_pub, w = trip
+    a, b, c = pyref.groth16_closed_form(A, B, C, n_row, n_col, n_pub, w, cv, TOXIC, BLIND)
+    g1, g2 = pyref.G1(cv), pyref.G2(cv)
+    return pyref.proof_bytes(cv, (g1.mul(g1.gen, a), g2.mul(g2.gen, b), g1.mul(g1.gen, c)))
+
+
+@pytest.mark.parametrize("curve", ["BN254", "BLS12_381"])
+@pytest.mark.parametrize("circuit", ["readme", "chain8", "chain256"])
+def test_proof_bytes_equal_closed_form(gpu, curve, circuit):
+    cv = pyref.curve_by_name(curve)
+    trip = pyref.readme_circuit(cv.r) if circuit == "readme" else pyref.chain_circuit(int(circuit[5:]), cv.r)
+    r1cs, w, n_pub = _r1cs(trip, curve)
+    assert r1cs.is_sat(w[:n_pub], w[n_pub:])
+    g = Groth16(r1cs, curve)
+    g._toxic, g._blinding = TOXIC, BLIND
+    g.setup()
+    proof = g.prove(w[:n_pub], w[n_pub:])
+    assert proof.to_bytes() == _oracle_proof_bytes(trip, cv)
+    assert g.verify(proof, w[:n_pub])
+    forged = list(w[:n_pub])
+    forged[1] = (forged[1] + 1) % cv.r
+    assert not g.verify(proof, forged)
+    # limb-array witness (the fast path) gives the same proof
+    proof2 = g.prove(N.ints_to_limbs(w[:n_pub]), N.ints_to_limbs(w[n_pub:]))
+    assert proof2.to_bytes() == proof.to_bytes()
+
+
+@pytest.mark.parametrize("curve", ["BN254", "BLS12_381"])
+def test_random_setup_prove_verify_and_serialization(gpu, curve):
+    cv = pyref.curve_by_name(curve)
+    r1cs, w, n_pub = _r1cs(pyref.chain_circuit(16, cv.r, inp=3), curve)
+    g = Groth16(r1cs, curve)
+    g.setup()
+    proof = g.prove(w[:n_pub], w[n_pub:])
+    assert g.verify(proof, w[:n_pub])
+    # the oracle's verifier (independent pairing) accepts the proof too
+    to_o = lambda p, grp: None if p.is_zero() else ((p.x, p.y) if grp == 1 else (tuple(p.x), tuple(p.y)))  # noqa: E731
+    vk = g.verifying_key
+    ovk = dict(alpha_1=to_o(vk.alpha_1, 1), beta_2=to_o(vk.beta_2, 2), gamma_2=to_o(vk.gamma_2, 2),
+               delta_2=to_o(vk.delta_2, 2), ic=[to_o(p, 1) for p in vk.ic])
+    assert pyref.groth16_verify(ovk, (to_o(proof.A, 1), to_o(proof.B, 2), to_o(proof.C, 1)), w[:n_pub], cv)
+    # byte layouts round-trip (reference tests/test_groth16.py:147-208)
+    pb = proof.to_bytes()
+    assert len(pb) == (128 if curve == "BN254" else 192)
+    assert Proof.from_bytes(pb, curve).to_bytes() == pb
+    kb = g.proving_key.to_bytes()
+    pk2 = ProvingKey.from_bytes(kb, curve)
+    assert pk2.to_bytes() == kb
+    vb = g.verifying_key.to_bytes()
+    assert VerifyingKey.from_bytes(vb, curve).to_bytes() == vb
+    # a prover restarted from serialized keys produces verifying proofs
+    g2 = Groth16(r1cs, curve)
+    g2.proving_key, g2.verifying_key = pk2, VerifyingKey.from_bytes(vb, curve)
+    assert g2.verify(g2.prove(w[:n_pub], w[n_pub:]), w[:n_pub])
+
+
+def test_bad_witness_and_assertions(gpu):
+    cv = pyref.BN254
+    r1cs, w, n_pub = _r1cs(pyref.chain_circuit(8, cv.r), "BN254")
+    g = Groth16(r1cs)
+    with pytest.raises(AssertionError, match="ProvingKey has not been generated"):
+        g.prove(w[:n_pub], w[n_pub:])
+    g.setup()
+    with pytest.raises(AssertionError, match="Length of kdelta_1 and private_witness must be equal"):
+        g.prove(w[:n_pub], w[n_pub:-1])
+    bad = list(w)
+    bad[4] = (bad[4] + 1) % cv.r
+    with pytest.raises(ValueError, match="Failed to evaluate with the given witness"):
+        g.prove(bad[:n_pub], bad[n_pub:])
+    proof = g.prove(w[:n_pub], w[n_pub:])
+    with pytest.raises(AssertionError, match="Length of IC and public_witness must be equal"):
+        g.verify(proof, w[:1])
+
+
+def test_multiexp_rules_and_batch_mul(gpu):
+    """EllipticCurve.multiexp truncation / empty / mismatch rules (reference ecc.py:107-126)"""
+    E = EllipticCurve("BN254")
+    G = E.G1()
+    pts = E.batch_mul(G, [1, 2, 3, 4])
+    assert pts[2] == G * 3
+    assert E.multiexp(pts, [5, 6, 7, 8]) == G * (5 + 12 + 21 + 32)
+    assert E.multiexp(pts, [5, 6]) == G * 17          # bases truncated to len(scalars)
+    assert E.multiexp(pts, []).is_zero()
+    with pytest.raises(ValueError, match="Number of points and scalars mismatch"):
+        E.multiexp(pts, [1, 2, 3, 4, 5])
+    arr = E.batch_mul(G, [1, 2, 3, 4], as_array=True)
+    assert E.multiexp(arr, [5, 6, 7, 8]) == G * 70 and E.multiexp(arr, [5, 6]) == G * 17
+    assert E.batch_mul([], []) == []
+    G2 = E.G2()
+    assert E.multiexp(E.batch_mul(G2, [3, 4]), [5, 6]) == G2 * 39
+
+
+def test_polynomial_front_end(gpu):
+    """the reference's polynomial identities (tests/test_algebra.py:6-46) plus fft round trips"""
+    from zksnake_amd.constant import BLS12_381_SCALAR_FIELD, BN254_SCALAR_FIELD
+    from zksnake_amd.polynomial import Polynomial, fft, ifft, mul_over_fft
+    for p in (BN254_SCALAR_FIELD, BLS12_381_SCALAR_FIELD):
+        a, b = Polynomial([1, 2, 3], p), Polynomial([2, 3, 4], p)
+        assert a + b == Polynomial([3, 5, 7], p)
+        assert b - a == Polynomial([1, 1, 1], p)
+        assert a * b == Polynomial([2, 7, 16, 17, 12], p)
+        assert mul_over_fft(4, a, b, p) == Polynomial([2, 7, 16, 17, 12], p)
+        assert ifft(fft([1, 2, 3, 4], p), p) == [1, 2, 3, 4]
+        hz = Polynomial([p - 1, 0, 0, 0, 1, 0, 0, 0, 5], p, 4)  # (x^4 - 1)(5x^4 + 6) ... remainder check
+        q, rem = Polynomial([p - 6, 0, 0, 0, 1, 0, 0, 0, 5], p, 4).divide_by_vanishing_poly()
+        assert q == Polynomial([6, 0, 0, 0, 5], p) and rem.is_zero()
+        q, rem = hz.divide_by_vanishing_poly()
+        assert not rem.is_zero()
+
+
+def test_groth16_chain_2_12(gpu):
+    """a mid-size instance of the benchmark circuit, limb-array witness, closed-form check of A, B, C"""
+    curve, cv = "BN254", pyref.BN254
+    n = 1 << 12
+    A, B, C, w, n_col = W.chain_circuit(n, cv.r)
+    r1cs = R1CS.from_triplets(A, B, C, n, n_col, 2, curve)
+    g = Groth16(r1cs, curve)
+    g._toxic, g._blinding = TOXIC, BLIND
+    g.setup()
+    proof = g.prove(N.ints_to_limbs(w[:2]), N.ints_to_limbs(w[2:]))
+    trip = (list(zip(*A)), list(zip(*B)), list(zip(*C)), n, n_col, 2, w)
+    assert proof.to_bytes() == _oracle_proof_bytes(trip, cv)

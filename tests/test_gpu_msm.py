@@ -1,0 +1,148 @@
+"""GPU parity: Pippenger MSM and batch scalar multiplication through the C ABI, all four groups,
+against the CPU oracle (bit-exact affine results), plus the 2^20 closed-form check of BASELINE config 2."""
+
+import numpy as np
+import pytest
+
+from helpers import CURVES, generator_limbs, oracle_bases, rand_limbs, rand_scalars
+from oracle import corc, pyref
+from zksnake_amd import _native as N
+from zksnake_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _msm(lib, cid, grp, sc, bases):
+    out = np.zeros(N.point_limbs(cid, grp), dtype=np.uint64)
+    N.check(lib.zk_msm(cid, grp, bases.shape[0], sc.shape[0], N.u64p(sc), N.u64p(bases), N.u64p(out)))
+    return out
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+@pytest.mark.parametrize("grp", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 7, 33, 1000])
+def test_msm_matches_oracle(gpu, name, cid, grp, n):
+    cv = pyref.curve_by_name(name)
+    _, bases = oracle_bases(cid, grp, n, 40 + n)
+    _, sc = rand_scalars(n, cv.r, 50 + n)
+    assert (_msm(gpu, cid, grp, sc, bases) == corc.msm(cid, grp, sc, bases, threads=8)).all()
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+@pytest.mark.parametrize("grp", [1, 2])
+def test_msm_edge_cases(gpu, name, cid, grp):
+    """zero / one / r-1 scalars, scalars >= r, duplicate bases, P and -P, the point at infinity as a base"""
+    cv = pyref.curve_by_name(name)
+    g = pyref.Group(cv, grp)
+    n = 24
+    ks, bases = oracle_bases(cid, grp, n, 60)
+    pts = corc.limbs_to_points(bases, cid, grp)
+    vals, _ = rand_scalars(n, cv.r, 61)
+    vals[0], vals[1], vals[2], vals[3] = 0, 1, cv.r - 1, cv.r + 7     # r + 7 must act like 7
+    pts[5] = pts[4]                                                   # duplicate base
+    pts[7] = g.neg(pts[6]); vals[7] = vals[6]                         # cancels exactly
+    pts[8] = None                                                     # infinity base
+    pts[10] = pts[9]; vals[10] = vals[9]                              # same point, same scalar -> doubling in a bucket
+    bases = corc.points_to_limbs(pts, cid, grp)
+    sc = N.ints_to_limbs(vals, 4)
+    exp = g.msm(pts, vals)
+    got = corc.limbs_to_points(_msm(gpu, cid, grp, sc, bases), cid, grp)[0]
+    assert got == exp
+    # all scalars zero -> infinity ; everything cancels -> infinity
+    zero = np.zeros((n, 4), dtype=np.uint64)
+    assert not _msm(gpu, cid, grp, zero, bases).any()
+    two = corc.points_to_limbs([pts[0], g.neg(pts[0])], cid, grp)
+    assert not _msm(gpu, cid, grp, N.ints_to_limbs([5, 5]), two).any()
+
+
+def test_msm_length_rules(gpu):
+    bases = np.zeros((3, 8), dtype=np.uint64)
+    sc = np.zeros((2, 4), dtype=np.uint64)
+    out = np.zeros(8, dtype=np.uint64)
+    assert gpu.zk_msm(0, 1, 3, 2, N.u64p(sc), N.u64p(bases), N.u64p(out)) == N.ZK_ERR_LENGTH
+    assert b"Number of points and scalars mismatch" in gpu.zk_last_error()
+    assert gpu.zk_msm(0, 1, 0, 0, N.u64p(sc), N.u64p(bases), N.u64p(out)) == N.ZK_OK and not out.any()
+    assert gpu.zk_msm(7, 1, 1, 1, N.u64p(sc), N.u64p(bases), N.u64p(out)) == N.ZK_ERR_ARG
+
+
+@pytest.mark.parametrize("c", [4, 7, 11, 13, 16])
+def test_msm_window_sizes_and_sharding(gpu, c):
+    """every window width gives the same point; partial results of disjoint window ranges add up"""
+    cid, grp, cv = 0, 1, pyref.BN254
+    n = 3000
+    _, bases = oracle_bases(cid, grp, n, 70)
+    _, sc = rand_scalars(n, cv.r, 71)
+    exp = corc.msm(cid, grp, sc, bases, threads=8)
+    h = N._u64(0)
+    N.check(gpu.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, 0, c, h))
+    try:
+        cb, nw = N._i(0), N._i(0)
+        N.check(gpu.zk_msm_plan_windows(h, cb, nw))
+        assert cb.value == c and nw.value * c >= 255
+        out = np.zeros(8, dtype=np.uint64)
+        N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, 0, 0, N.u64p(out), None))
+        assert (out == exp).all()
+        from zksnake_amd.parallel import sum_points, window_ranges
+        for world in (2, 3, 8):
+            parts = []
+            for first, count in window_ranges(nw.value, world):
+                part = np.zeros(8, dtype=np.uint64)
+                if count:
+                    N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, first, count, N.u64p(part), None))
+                parts.append(part)
+            assert (sum_points(cid, grp, parts) == exp).all()
+        # fewer scalars than bases: the first k bases are used (ecc.py:118-119)
+        N.check(gpu.zk_msm_plan_run(h, 100, sc.ctypes.data, 0, 0, 0, N.u64p(out), None))
+        assert (out == corc.msm(cid, grp, sc[:100], bases[:100], threads=8)).all()
+        tm = (N.ctypes.c_float * 5)()
+        assert gpu.zk_msm_plan_timings(h, tm, 5) == 5 and tm[1] > 0
+    finally:
+        N.check(gpu.zk_msm_plan_destroy(h))
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+@pytest.mark.parametrize("grp", [1, 2])
+def test_batch_mul(gpu, name, cid, grp):
+    cv = pyref.curve_by_name(name)
+    gen = generator_limbs(gpu, cid, grp)
+    vals, sc = rand_scalars(50, cv.r, 80)
+    vals[:4] = [0, 1, cv.r - 1, 2]
+    sc = N.ints_to_limbs(vals, 4)
+    out = np.zeros((50, N.point_limbs(cid, grp)), dtype=np.uint64)
+    N.check(gpu.zk_batch_mul(cid, grp, 50, N.u64p(sc), N.u64p(gen), 1, N.u64p(out)))
+    exp = corc.batch_mul(cid, grp, sc, gen)
+    assert (out == exp).all()
+    # per-element bases
+    out2 = np.zeros_like(out)
+    N.check(gpu.zk_batch_mul(cid, grp, 50, N.u64p(sc), N.u64p(exp), 0, N.u64p(out2)))
+    assert (out2 == corc.batch_mul(cid, grp, sc, exp)).all()
+
+
+def _known_dl_case(gpu, n, scalars_limbs, scalar_ints):
+    cid, grp, r = 0, 1, pyref.BN254.r
+    k_limbs, k_ints = W.field_stream(W.SEED_MSM_BASES, n, r)
+    gen = generator_limbs(gpu, cid, grp)
+    bases = np.zeros((n, 8), dtype=np.uint64)
+    N.check(gpu.zk_batch_mul(cid, grp, n, N.u64p(k_limbs), N.u64p(gen), 1, N.u64p(bases)))
+    dot = sum(a * b for a, b in zip(scalar_ints, k_ints)) % r
+    exp = np.zeros(8, dtype=np.uint64)
+    N.check(gpu.zk_point_mul(cid, grp, N.u64p(gen), N.u64p(N.ints_to_limbs([dot])), N.u64p(exp)))
+    assert (_msm(gpu, cid, grp, scalars_limbs, bases) == exp).all()
+
+
+def test_msm_2_20_closed_form(gpu):
+    """BASELINE config 2 at full size: MSM(s, k_i G) == (sum s_i k_i mod r) G"""
+    n = 1 << 20
+    sc_limbs, sc_ints = W.field_stream(W.SEED_MSM_SCALARS, n, pyref.BN254.r)
+    _known_dl_case(gpu, n, sc_limbs, sc_ints)
+
+
+def test_msm_skewed_scalars(gpu):
+    """benchmark-witness-like single-bit scalars and one hot bucket (SURVEY 8d skew variant)"""
+    n = 1 << 16
+    limbs, ints = W.powers_of_two_scalars(n, pyref.BN254.r)
+    _known_dl_case(gpu, n, limbs, ints)
+    ones = [1] * n
+    _known_dl_case(gpu, n, N.ints_to_limbs(ones), ones)
+    same = [0xDEADBEEFCAFEBABE1234567] * n
+    _known_dl_case(gpu, n, N.ints_to_limbs(same), same)

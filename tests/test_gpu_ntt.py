@@ -1,0 +1,167 @@
+"""GPU parity: NTT / iNTT / coset / vector ops / vanishing division / fused QAP pipeline through the C ABI,
+against the CPU oracle on the same seeded inputs (bit-exact), plus size-independent properties at 2^22."""
+
+import numpy as np
+import pytest
+
+from helpers import CURVES, rand_limbs, rand_scalars
+from oracle import corc, pyref
+from zksnake_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+
+
+def _ntt(lib, cid, a, size, inverse=0, coset=0):
+    n = 1 if size <= 1 else 1 << (size - 1).bit_length()
+    out = np.zeros((n, 4), dtype=np.uint64)
+    N.check(lib.zk_ntt(cid, inverse, coset, a.shape[0], N.u64p(a), size, N.u64p(out)))
+    return out
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 9, 10, 11, 13, 16])
+def test_ntt_matches_oracle(gpu, name, cid, log_n):
+    cv = pyref.curve_by_name(name)
+    n = 1 << log_n
+    _, a = rand_scalars(n, cv.r, 100 + log_n)
+    assert (_ntt(gpu, cid, a, n) == corc.ntt(cid, a)).all()
+    assert (_ntt(gpu, cid, a, n, inverse=1) == corc.ntt(cid, a, inverse=True)).all()
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+def test_ntt_kat_and_definition(gpu, name, cid):
+    cv = pyref.curve_by_name(name)
+    # SURVEY Appendix A known-answer vector
+    got = N.limbs_to_ints(_ntt(gpu, cid, N.ints_to_limbs([1, 2, 3, 4]), 4))
+    assert got == pyref.ntt([1, 2, 3, 4], 4, cv)
+    vals, a = rand_scalars(64, cv.r, 5)
+    assert N.limbs_to_ints(_ntt(gpu, cid, a, 64)) == pyref.dft_naive(vals, 64, cv)
+    assert N.limbs_to_ints(_ntt(gpu, cid, a, 64, inverse=1)) == pyref.dft_naive(vals, 64, cv, inverse=True)
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+def test_ntt_padding_folding_reduction(gpu, name, cid):
+    cv = pyref.curve_by_name(name)
+    vals, a = rand_scalars(5, cv.r, 6)
+    # shorter input is zero-padded, size rounded up to a power of two
+    assert N.limbs_to_ints(_ntt(gpu, cid, a, 6)) == pyref.ntt(vals, 8, cv)
+    # longer input folds modulo X^n - 1
+    vals, a = rand_scalars(11, cv.r, 7)
+    assert N.limbs_to_ints(_ntt(gpu, cid, a, 4)) == pyref.ntt(vals, 4, cv)
+    # values >= r are reduced on entry (Fr::from(BigUint))
+    big = [cv.r + 5, 2 * cv.r + 1, (1 << 256) - 1, 0]
+    assert N.limbs_to_ints(_ntt(gpu, cid, N.ints_to_limbs(big), 4)) == pyref.ntt([b % cv.r for b in big], 4, cv)
+    # empty input
+    assert N.limbs_to_ints(_ntt(gpu, cid, np.zeros((0, 4), dtype=np.uint64), 4)) == [0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+def test_coset_ntt(gpu, name, cid):
+    cv = pyref.curve_by_name(name)
+    vals, a = rand_scalars(32, cv.r, 8)
+    assert N.limbs_to_ints(_ntt(gpu, cid, a, 32, coset=1)) == pyref.coset_ntt(vals, 32, cv)
+    assert N.limbs_to_ints(_ntt(gpu, cid, a, 32, inverse=1, coset=1)) == pyref.coset_ntt(vals, 32, cv, inverse=True)
+
+
+def test_domain_too_large(gpu):
+    a = np.zeros((1, 4), dtype=np.uint64)
+    out = np.zeros((1, 4), dtype=np.uint64)
+    assert gpu.zk_ntt(0, 0, 0, 1, N.u64p(a), 1 << 29, N.u64p(out)) == N.ZK_ERR_DOMAIN  # BN254 two-adicity 28
+    assert b"too large" in gpu.zk_last_error()
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+def test_vec_ops(gpu, name, cid):
+    cv = pyref.curve_by_name(name)
+    va, a = rand_scalars(777, cv.r, 9)
+    vb, b = rand_scalars(500, cv.r, 10)
+    for op, fn in ((0, lambda x, y: x * y), (1, lambda x, y: x + y), (2, lambda x, y: x - y)):
+        out = np.zeros((777, 4), dtype=np.uint64)
+        N.check(gpu.zk_vec_op(cid, op, 777, 777, N.u64p(a), 500, N.u64p(b), N.u64p(out)))
+        exp = [fn(x, vb[i] if i < 500 else 0) % cv.r for i, x in enumerate(va)]
+        assert N.limbs_to_ints(out) == exp
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+@pytest.mark.parametrize("n,ln", [(8, 5), (8, 8), (8, 13), (8, 16), (8, 27), (16, 31)])
+def test_divide_by_vanishing(gpu, name, cid, n, ln):
+    cv = pyref.curve_by_name(name)
+    vals, a = rand_scalars(ln, cv.r, 11 + ln)
+    q = np.zeros((max(ln - n, 1), 4), dtype=np.uint64)
+    rem = np.zeros((min(ln, n), 4), dtype=np.uint64)
+    flag = N._i(0)
+    N.check(gpu.zk_poly_div_vanishing(cid, n, ln, N.u64p(a), N.u64p(q), N.u64p(rem), flag))
+    eq, er = pyref.divide_by_vanishing(vals, n, cv.r)
+    assert pyref.strip_zeros(N.limbs_to_ints(q[: max(ln - n, 0)])) == eq
+    assert pyref.strip_zeros(N.limbs_to_ints(rem)) == er
+    assert flag.value == (0 if er else 1)
+
+
+def test_ntt_2_22_properties(gpu):
+    """BASELINE config 3 size: round trip, linearity, and spot evaluation against Horner"""
+    import ctypes
+    cid, cv, log_n = 0, pyref.BN254, 22
+    n = 1 << log_n
+    a = rand_limbs(n, 22)
+    d = ctypes.c_void_p()
+    N.check(gpu.zk_dev_alloc(n * 32, ctypes.byref(d)))
+    try:
+        N.check(gpu.zk_dev_upload(d, a.ctypes.data, a.nbytes))
+        N.check(gpu.zk_ntt_dev(cid, 0, log_n, d, None))
+        fwd = np.empty_like(a)
+        N.check(gpu.zk_dev_download(fwd.ctypes.data, d, a.nbytes))
+        N.check(gpu.zk_ntt_dev(cid, 1, log_n, d, None))
+        back = np.empty_like(a)
+        N.check(gpu.zk_dev_download(back.ctypes.data, d, a.nbytes))
+    finally:
+        gpu.zk_dev_free(d)
+    assert (back == a).all()
+    # spot values: out[k] = sum_j a_j w^(jk); k = 0 is the plain sum, k = n/2 the alternating sum
+    ints = N.limbs_to_ints(a)
+    r = cv.r
+    assert N.limbs_to_ints(fwd[0:1])[0] == sum(ints) % r
+    assert N.limbs_to_ints(fwd[n // 2:n // 2 + 1])[0] == (sum(ints[0::2]) - sum(ints[1::2])) % r
+    k = 123457
+    assert N.limbs_to_ints(fwd[k:k + 1])[0] == pyref.poly_eval(ints, pow(cv.root_of_unity(n), k, r), r)
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+@pytest.mark.parametrize("n", [2, 16, 1024])
+def test_qap_pipeline_matches_oracle(gpu, name, cid, n):
+    from zksnake_amd.device import DeviceBuffer
+    cv = pyref.curve_by_name(name)
+    A, B, C, n_row, n_col, n_pub, w = pyref.chain_circuit(n, cv.r)
+    a = N.ints_to_limbs(pyref.sparse_dot(A, n_row, w, cv.r))
+    b = N.ints_to_limbs(pyref.sparse_dot(B, n_row, w, cv.r))
+    c = N.ints_to_limbs(pyref.sparse_dot(C, n_row, w, cv.r))
+    eu, ev, eh = corc.qap_h(cid, a, b, c)
+    da, db, dc = DeviceBuffer.from_numpy(a), DeviceBuffer.from_numpy(b), DeviceBuffer.from_numpy(c)
+    dh, dw = DeviceBuffer(n * 32), DeviceBuffer(4 * n * 32)
+    ok = N._i(0)
+    N.check(gpu.zk_qap_h_dev(cid, n.bit_length() - 1, da.ptr, db.ptr, dc.ptr, dh.ptr, dw.ptr, ok, None))
+    assert ok.value == 1
+    assert (da.download((n, 4)) == eu).all() and (db.download((n, 4)) == ev).all() and (dh.download((n, 4)) == eh).all()
+    # a wrong witness leaves a remainder
+    bad = a.copy()
+    bad[0, 0] ^= np.uint64(1)
+    da.upload(bad); db.upload(b)
+    N.check(gpu.zk_qap_h_dev(cid, n.bit_length() - 1, da.ptr, db.ptr, dc.ptr, dh.ptr, dw.ptr, ok, None))
+    assert ok.value == 0
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+def test_spmv(gpu, name, cid):
+    from zksnake_amd.array import SparseArray
+    from zksnake_amd.device import DeviceBuffer
+    import random
+    cv = pyref.curve_by_name(name)
+    rnd = random.Random(3)
+    n_row, n_col = 37, 23
+    trip = [(rnd.randrange(n_row), rnd.randrange(n_col), rnd.randrange(cv.r)) for _ in range(200)]
+    m = SparseArray.from_triplets(*zip(*trip), n_row, n_col, cv.r)
+    w = [rnd.randrange(cv.r) for _ in range(n_col)]
+    rp, cl, vl = m.to_csr()
+    bufs = [DeviceBuffer.from_numpy(x) for x in (rp, cl, vl, N.ints_to_limbs(w))]
+    out = DeviceBuffer(n_row * 32)
+    N.check(gpu.zk_spmv_dev(cid, n_row, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, out.ptr, None))
+    assert N.limbs_to_ints(out.download((n_row, 4))) == m.dot(w) == pyref.sparse_dot(trip, n_row, w, cv.r)

@@ -43,6 +43,13 @@ SIGNATURES = {
     "zk_device_count": (_i, []),
     "zk_last_error": (ctypes.c_char_p, []),
     "zk_version": (ctypes.c_char_p, []),
+    "zk_dev_alloc": (_i, [_u64, ctypes.POINTER(_vp)]),
+    "zk_dev_free": (_i, [_vp]),
+    "zk_dev_upload": (_i, [_vp, _vp, _u64]),
+    "zk_dev_download": (_i, [_vp, _vp, _u64]),
+    "zk_dev_memset": (_i, [_vp, _i, _u64]),
+    "zk_dev_synchronize": (_i, []),
+    "zk_spmv_dev": (_i, [_i, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "zk_fq_limbs": (_i, [_i]),
     "zk_point_limbs": (_i, [_i, _i]),
     "zk_ntt": (_i, [_i, _i, _i, _u64, _u64p, _u64, _u64p]),

@@ -1,0 +1,146 @@
+"""
+R1CS object with the shape the prover consumes (reference python/zksnake/arithmetization/r1cs.py:11-122):
+attributes A, B, C (SparseArray), n_public, p; `is_sat`; `from_file` for circom `.r1cs` binaries.
+
+The reference builds A, B, C by compiling its symbolic ConstraintSystem (Rust, O(n^2), out of scope here);
+this class is filled directly from matrices (`from_matrices`), from triplet lists, or from a circom file
+whose matrices are kept verbatim in circom wire order (proofs do not depend on the wire order).
+"""
+
+from ..array import SparseArray
+from ..ecc import EllipticCurve
+
+
+class R1CS:
+    def __init__(self, cs=None, curve: str = "BN254"):
+        self.A = None
+        self.B = None
+        self.C = None
+        self.constraint_system = cs
+        self.curve = curve
+        self.n_public = (len(cs.public_vars) + 1) if cs is not None else 1
+        self.p = EllipticCurve(curve).order
+
+    # ---- construction -------------------------------------------------------------------------
+    @classmethod
+    def from_triplets(cls, A, B, C, n_row, n_col, n_public, curve="BN254"):
+        """A, B, C: (rows, cols, vals) triples of equal-length sequences."""
+        self = cls(None, curve)
+        self.A = SparseArray.from_triplets(*A, n_row, n_col, self.p)
+        self.B = SparseArray.from_triplets(*B, n_row, n_col, self.p)
+        self.C = SparseArray.from_triplets(*C, n_row, n_col, self.p)
+        self.n_public = n_public
+        return self
+
+    @classmethod
+    def from_matrices(cls, A, B, C, n_public, curve="BN254"):
+        """dense row lists (tests / tiny circuits)"""
+        self = cls(None, curve)
+        n_row, n_col = len(A), len(A[0])
+        self.A = SparseArray(A, n_row, n_col, self.p)
+        self.B = SparseArray(B, n_row, n_col, self.p)
+        self.C = SparseArray(C, n_row, n_col, self.p)
+        for m in (self.A, self.B, self.C):
+            m.triplets = [(r, c, v % self.p) for r, c, v in m.triplets]
+        self.n_public = n_public
+        return self
+
+    def compile(self):
+        """compile the attached constraint system (must expose the reference's compile_to_r1cs() /
+        num_constraints() / num_witness() protocol, arithmetization/r1cs.py:21-40)."""
+        if self.constraint_system is None:
+            if self.A is None:
+                raise ValueError("no constraint system attached")
+            return
+        cs = self.constraint_system
+        rows, cols = cs.num_constraints(), cs.num_witness() + 1
+        self.A = SparseArray([[]], rows, cols, self.p)
+        self.B = SparseArray([[]], rows, cols, self.p)
+        self.C = SparseArray([[]], rows, cols, self.p)
+        for a, b, c in cs.compile_to_r1cs():
+            self.A.append(a)
+            self.B.append(b)
+            self.C.append(c)
+
+    def solve(self, inputs: dict) -> dict:
+        if self.constraint_system is None:
+            raise NotImplementedError("no symbolic constraint system attached; supply the witness directly")
+        return self.constraint_system.solve(inputs)
+
+    def generate_witness(self, solve_result: dict):
+        if self.constraint_system is None:
+            raise NotImplementedError("no symbolic constraint system attached; supply the witness directly")
+        w = []
+        for v in self.constraint_system.get_witness_vector():
+            if v == "0":
+                w.append(1)
+            elif isinstance(v, str):
+                w.append(solve_result[v] % self.p)
+            else:
+                w.append(v % self.p)
+        return w[: self.n_public], w[self.n_public:]
+
+    def is_sat(self, public_witness: list, private_witness: list):
+        assert self.A is not None, "R1CS is not compiled"
+        w = list(public_witness) + list(private_witness)
+        az, bz, cz = self.A.dot(w), self.B.dot(w), self.C.dot(w)
+        return [x * y % self.p for x, y in zip(az, bz)] == cz
+
+    def to_bytes(self):
+        raise NotImplementedError
+
+    @classmethod
+    def from_bytes(cls, data):
+        raise NotImplementedError
+
+    # ---- circom .r1cs (binary format v1) --------------------------------------------------------
+    @classmethod
+    def from_file(cls, r1csfile: str, symfile: str = None, curve: str = "BN254"):
+        """Load A, B, C from a circom `.r1cs` file.  Sections: 1 header, 2 constraints, 3 wire map.
+        Wires: [1, public outputs, public inputs, private inputs, intermediates]; n_public counts the
+        constant wire plus the public outputs and inputs (reference r1cs.py:94-122, parser.py:10-219)."""
+        del symfile  # labels are not needed for the matrices
+        with open(r1csfile, "rb") as f:
+            data = f.read()
+        if data[:4] != b"r1cs":
+            raise AssertionError(f"Invalid magic bytes: {data[:4]}")
+        version = int.from_bytes(data[4:8], "little")
+        if version != 1:
+            raise AssertionError(f"Unsupported r1cs file version: {version}")
+        n_sections = int.from_bytes(data[8:12], "little")
+        pos = 12
+        sections = {}
+        for _ in range(n_sections):
+            kind = int.from_bytes(data[pos:pos + 4], "little")
+            size = int.from_bytes(data[pos + 4:pos + 12], "little")
+            sections[kind] = data[pos + 12:pos + 12 + size]
+            pos += 12 + size
+        hdr = sections[1]
+        fs = int.from_bytes(hdr[0:4], "little")
+        prime = int.from_bytes(hdr[4:4 + fs], "little")
+        o = 4 + fs
+        n_wires, n_pub_out, n_pub_in, n_priv_in = (int.from_bytes(hdr[o + 4 * k:o + 4 * k + 4], "little") for k in range(4))
+        m_constraints = int.from_bytes(hdr[o + 24:o + 28], "little")
+        self = cls(None, curve)
+        if prime != self.p:
+            raise ValueError("the .r1cs file is over a different field than the selected curve")
+        body = sections[2]
+        pos = 0
+        mats = ([], [], [])
+        for row in range(m_constraints):
+            for k in range(3):
+                nterms = int.from_bytes(body[pos:pos + 4], "little")
+                pos += 4
+                for _ in range(nterms):
+                    wire = int.from_bytes(body[pos:pos + 4], "little")
+                    val = int.from_bytes(body[pos + 4:pos + 4 + fs], "little")
+                    pos += 4 + fs
+                    if val:
+                        mats[k].append((row, wire, val))
+        for name, trip in zip("ABC", mats):
+            rows, cols, vals = (list(t) for t in zip(*trip)) if trip else ([], [], [])
+            setattr(self, name, SparseArray.from_triplets(rows, cols, vals, m_constraints, n_wires, self.p))
+        self.n_public = 1 + n_pub_out + n_pub_in
+        self.header = dict(n_wires=n_wires, n_pub_out=n_pub_out, n_pub_in=n_pub_in, n_priv_in=n_priv_in,
+                           m_constraints=m_constraints, prime=prime)
+        return self

@@ -1,0 +1,70 @@
+"""
+Sparse matrix in triplet form, the input contract of the proving path
+(same attributes as the reference's python/zksnake/array.py:4-44).
+
+`dot` keeps the reference's host-side semantics for small systems; `to_csr` produces the arrays
+the GPU SpMV kernel (zk_spmv_dev) consumes so that A.w, B.w, C.w of a 2^20-row system never
+loop in Python.
+"""
+
+import numpy as np
+
+from . import _native as N
+
+
+class SparseArray:
+    def __init__(self, matrix, n_row, n_col, p):
+        self.p = p
+        self.n_row = n_row
+        self.n_col = n_col
+        self.triplets = []
+        self.triplets_map = {}
+        self._csr = None
+        for i, row in enumerate(matrix):
+            for j, value in enumerate(row):
+                if value != 0:
+                    self.triplets.append((i, j, value))
+
+    @classmethod
+    def from_triplets(cls, rows, cols, vals, n_row, n_col, p):
+        """bulk constructor (no per-entry Python work beyond one zip)"""
+        self = cls([], n_row, n_col, p)
+        self.triplets = list(zip(rows, cols, vals))
+        return self
+
+    def append(self, triplets):
+        for row, col, value in triplets:
+            if value != 0:
+                self.triplets_map.setdefault(row, []).append((col, value))
+                self.triplets.append((row, col, value))
+        self._csr = None
+
+    def rows_map(self):
+        """row -> [(col, value)] (built on demand when the matrix came from from_triplets)"""
+        if len(self.triplets_map) == 0 and self.triplets:
+            m = {}
+            for row, col, value in self.triplets:
+                m.setdefault(row, []).append((col, value))
+            self.triplets_map = m
+        return self.triplets_map
+
+    def dot(self, vector):
+        out = [0] * self.n_row
+        for row, col, value in self.triplets:
+            out[row] += vector[col] * value
+        return [x % self.p for x in out]
+
+    def to_csr(self):
+        """(row_ptr uint32[n_row+1], cols uint32[nnz], vals uint64[nnz,4]) with rows padded to n_row"""
+        if self._csr is None:
+            nnz = len(self.triplets)
+            rows = np.fromiter((t[0] for t in self.triplets), dtype=np.int64, count=nnz)
+            cols = np.fromiter((t[1] for t in self.triplets), dtype=np.int64, count=nnz)
+            order = np.argsort(rows, kind="stable")
+            counts = np.bincount(rows, minlength=self.n_row)
+            row_ptr = np.zeros(self.n_row + 1, dtype=np.uint32)
+            np.cumsum(counts, out=row_ptr[1:])
+            p = self.p
+            vals = N.ints_to_limbs([self.triplets[k][2] % p for k in order], 4)
+            self._csr = (row_ptr, cols[order].astype(np.uint32), vals)
+        return self._csr

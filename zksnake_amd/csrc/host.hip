@@ -297,6 +297,31 @@ int zk_shutdown(void) {
     return ZK_OK;
 }
 
+int zk_dev_alloc(uint64_t bytes, void** d_ptr) {
+    ZK_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return ZK_OK;
+}
+int zk_dev_free(void* d_ptr) {
+    ZK_HIP(hipFree(d_ptr));
+    return ZK_OK;
+}
+int zk_dev_upload(void* d_dst, const void* h_src, uint64_t bytes) {
+    if (bytes) ZK_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return ZK_OK;
+}
+int zk_dev_download(void* h_dst, const void* d_src, uint64_t bytes) {
+    if (bytes) ZK_HIP(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return ZK_OK;
+}
+int zk_dev_memset(void* d_dst, int value, uint64_t bytes) {
+    if (bytes) ZK_HIP(hipMemset(d_dst, value, bytes));
+    return ZK_OK;
+}
+int zk_dev_synchronize(void) {
+    ZK_HIP(hipDeviceSynchronize());
+    return ZK_OK;
+}
+
 const char* zk_last_error(void) { return last_error_ref().c_str(); }
 const char* zk_version(void) { return "zkmi 0.1 (gfx950)"; }
 

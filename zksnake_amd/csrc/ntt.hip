@@ -194,6 +194,23 @@ __global__ void div_vanishing_kernel(uint64_t n, uint64_t len, const uint32_t* c
     }
 }
 
+// CSR sparse matrix-vector product over Fr, one lane per row: out[row] = sum vals[k] * w[cols[k]].
+// Canonical in/out: mont(mont(v, x), R^2) = v*x; the sum is accumulated in Montgomery-by-R^-1 form
+// and fixed up once per row.
+template <class P>
+__global__ void spmv_kernel(uint64_t n_rows, const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ cols,
+                            const uint32_t* __restrict__ vals, const uint32_t* __restrict__ w, uint32_t* __restrict__ out) {
+    uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    Fp<P> acc = fp_zero<P>();
+    for (uint32_t k = row_ptr[row]; k < row_ptr[row + 1]; ++k) {
+        Fp<P> v = load_fr<P>(vals + (size_t)k * P::N);
+        Fp<P> x = load_fr<P>(w + (size_t)cols[k] * P::N);
+        acc = fp_add<P>(acc, fp_mul<P>(v, x));  // v*x/R
+    }
+    store_fr<P>(out + row * P::N, fp_mul<P>(acc, fp_const<P>(P::R2)));
+}
+
 // QAP tail: flag |= (lo[i] + hi[i] - w[i] != 0)
 template <class P>
 __global__ void qap_check_kernel(uint64_t n, const uint32_t* lo, const uint32_t* hi, const uint32_t* w, int* nonzero) {
@@ -460,6 +477,21 @@ int zk_vec_op_dev(int curve, int op, uint64_t n, const void* d_a, const void* d_
 
 int zk_qap_h_dev(int curve, int log_n, void* d_a_u, void* d_b_v, const void* d_c, void* d_h, void* d_work, int* divisible, void* stream) {
 #define CALL(P) return qap_h_dev_impl<P>(curve, log_n, (uint32_t*)d_a_u, (uint32_t*)d_b_v, (const uint32_t*)d_c, (uint32_t*)d_h, (uint32_t*)d_work, divisible, (hipStream_t)stream)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_spmv_dev(int curve, uint64_t n_rows, const void* d_row_ptr, const void* d_cols, const void* d_vals,
+                const void* d_w, void* d_out, void* stream) {
+    if (n_rows == 0) return ZK_OK;
+#define CALL(P)                                                                                                  \
+    {                                                                                                            \
+        hipLaunchKernelGGL(spmv_kernel<P>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, \
+                           n_rows, (const uint32_t*)d_row_ptr, (const uint32_t*)d_cols, (const uint32_t*)d_vals,  \
+                           (const uint32_t*)d_w, (uint32_t*)d_out);                                               \
+        ZK_HIP(hipGetLastError());                                                                               \
+        return ZK_OK;                                                                                            \
+    }
     ZK_DISPATCH_FR(curve, CALL);
 #undef CALL
 }

@@ -1,0 +1,48 @@
+"""Thin RAII wrapper over the library's device allocator (zk_dev_* in include/zkmi.h)."""
+
+import ctypes
+
+import numpy as np
+
+from . import _native as N
+
+
+class DeviceBuffer:
+    def __init__(self, nbytes):
+        lib = N.ensure_gpu()
+        ptr = ctypes.c_void_p()
+        N.check(lib.zk_dev_alloc(nbytes, ctypes.byref(ptr)))
+        self.ptr = ptr.value
+        self.nbytes = nbytes
+
+    @classmethod
+    def from_numpy(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = cls(arr.nbytes)
+        buf.upload(arr)
+        return buf
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        N.check(N.load().zk_dev_upload(self.ptr + offset, arr.ctypes.data, arr.nbytes))
+
+    def download(self, shape, dtype=np.uint64, offset=0):
+        out = np.empty(shape, dtype=dtype)
+        assert offset + out.nbytes <= self.nbytes
+        N.check(N.load().zk_dev_download(out.ctypes.data, self.ptr + offset, out.nbytes))
+        return out
+
+    def zero(self):
+        N.check(N.load().zk_dev_memset(self.ptr, 0, self.nbytes))
+
+    def free(self):
+        if self.ptr:
+            N.load().zk_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass

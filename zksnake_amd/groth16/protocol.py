@@ -1,0 +1,153 @@
+"""
+Groth16 setup / prove / verify with the reference's class surface
+(python/zksnake/groth16/protocol.py:14-186).  prove() keeps everything between the witness upload
+and the five MSM results on the GPU:
+
+    witness -> [SpMV x3] -> a, b, c -> [iNTT x3, NTT(2n) x2, mul, iNTT(2n), fold] -> u, v, h   (qap.py)
+    A  = <tau_1, u> + alpha_1 + r delta_1          B1 = <tau_1, v> + beta_1 + s delta_1
+    B2 = <tau_2, v> + beta_2 + s delta_2           C  = <target_1, h> + <kdelta_1, w_priv> + s A + r B1 - r s delta_1
+
+The proving key vectors are `PointArray`s whose Montgomery-form bases stay resident in HBM
+(MSM plans), so a prove moves one witness up and three points down.
+"""
+
+import numpy as np
+
+from .. import _native as N
+from ..arithmetization.r1cs import R1CS
+from ..ecc import EllipticCurve, PointArray
+from ..polynomial import POLY_OBJECT
+from ..utils import get_random_int
+from .qap import QAP
+from .serialization import Proof, ProvingKey, VerifyingKey
+
+
+def _as_array(E, pts, group):
+    """lists coming from ProvingKey.from_bytes become device-backed arrays on first use"""
+    if isinstance(pts, PointArray):
+        return pts
+    from .._algebra import _points_to_limbs
+    cid = E.curve.curve_id
+    return PointArray(cid, group, _points_to_limbs(pts, cid, group))
+
+
+class Groth16:
+    def __init__(self, r1cs: R1CS, curve: str = "BN254"):
+        self.E = EllipticCurve(curve)
+        self.order = self.E.order
+        self.qap = QAP(self.order)
+        self.qap.from_r1cs(r1cs)
+        self.proving_key = None
+        self.verifying_key = None
+        self._toxic = None      # tests may pin (tau, alpha, beta, gamma, delta)
+        self._blinding = None   # tests may pin (r, s)
+        self.last_timings = {}
+
+    # ------------------------------------------------------------------------------------------
+    def setup(self):
+        """trusted setup: ProvingKey and VerifyingKey from fresh (or pinned) toxic waste"""
+        q = self.order
+        G1, G2 = self.E.G1(), self.E.G2()
+        if self._toxic is not None:
+            tau, alpha, beta, gamma, delta = self._toxic
+        else:
+            tau, alpha, beta, gamma, delta = (get_random_int(q - 1) for _ in range(5))
+        inv_gamma, inv_delta = pow(gamma, -1, q), pow(delta, -1, q)
+
+        n = self.qap.a.n_row
+        n_wires = self.qap.a.n_col
+        mod = POLY_OBJECT[q]
+        lagrange = mod.evaluate_lagrange_coefficients(n, tau)
+
+        # per-wire QAP polynomials at tau: L_j = sum_i lagrange_i A[i][j], likewise R (B) and O (C)
+        L, R, O = [0] * n_wires, [0] * n_wires, [0] * n_wires
+        for acc, mat in ((L, self.qap.a), (R, self.qap.b), (O, self.qap.c)):
+            for row, col, value in mat.triplets:
+                acc[col] += lagrange[row] * value
+        K = [(L[j] * beta + R[j] * alpha + O[j]) % q for j in range(n_wires)]
+
+        t = mod.evaluate_vanishing_polynomial(n, tau)
+        powers = [1] * n
+        for i in range(1, n):
+            powers[i] = powers[i - 1] * tau % q
+        t_over_delta = t * inv_delta % q
+        shifted = [x * t_over_delta % q for x in powers]
+
+        n_pub = self.qap.n_public
+        tau_G1 = self.E.batch_mul(G1, powers, as_array=True)
+        tau_G2 = self.E.batch_mul(G2, powers, as_array=True)
+        target_G1 = self.E.batch_mul(G1, shifted, as_array=True)
+        k_gamma_G1 = self.E.batch_mul(G1, [k * inv_gamma % q for k in K[:n_pub]], as_array=True)
+        k_delta = [k * inv_delta % q for k in K[n_pub:]]
+        k_delta_G1 = self.E.batch_mul(G1, k_delta, as_array=True) if k_delta else []
+
+        alpha_G1, beta_G1, delta_G1 = G1 * alpha, G1 * beta, G1 * delta
+        beta_G2, gamma_G2, delta_G2 = G2 * beta, G2 * gamma, G2 * delta
+        self.proving_key = ProvingKey(alpha_G1, beta_G1, beta_G2, delta_G1, delta_G2, tau_G1, tau_G2, target_G1, k_delta_G1)
+        self.verifying_key = VerifyingKey(alpha_G1, beta_G2, gamma_G2, delta_G2, k_gamma_G1)
+
+    # ------------------------------------------------------------------------------------------
+    def _msm_dev(self, bases, group, d_scalars, count):
+        """<bases[:count], scalars> with scalars already in HBM"""
+        lib = N.load()
+        cid = self.E.curve.curve_id
+        arr = _as_array(self.E, bases, group)
+        out = np.zeros(N.point_limbs(cid, group), dtype=np.uint64)
+        N.check(lib.zk_msm_plan_run(arr.plan(), count, d_scalars, 1, 0, 0, N.u64p(out), None))
+        from .._algebra import _point_class
+        return arr, _point_class(cid, group)._from_limbs(out)
+
+    def prove(self, public_witness, private_witness) -> Proof:
+        """public_witness / private_witness: lists of ints (reference API) or (k, 4) uint64 limb arrays."""
+        assert self.proving_key, "ProvingKey has not been generated"
+        pk = self.proving_key
+        assert len(pk.kdelta_1) == len(private_witness), "Length of kdelta_1 and private_witness must be equal"
+        q = self.order
+        if self._blinding is not None:
+            r, s = self._blinding
+        else:
+            r, s = get_random_int(q - 1), get_random_int(q - 1)
+
+        if isinstance(public_witness, np.ndarray) or isinstance(private_witness, np.ndarray):
+            pub = public_witness if isinstance(public_witness, np.ndarray) else N.ints_to_limbs(public_witness, 4, q)
+            prv = private_witness if isinstance(private_witness, np.ndarray) else N.ints_to_limbs(private_witness, 4, q)
+            witness = np.concatenate([pub.reshape(-1, 4), prv.reshape(-1, 4)], axis=0)
+        else:
+            witness = list(public_witness) + list(private_witness)
+        try:
+            res = self.qap.evaluate_witness_device(witness)
+        except ValueError as exc:
+            raise ValueError("Failed to evaluate with the given witness") from exc
+
+        n = res.n
+        n_pub = self.qap.n_public
+        n_priv = len(private_witness)
+        pk.tau_1, msm_u = self._msm_dev(pk.tau_1, 1, res.u.ptr, min(n, len(pk.tau_1)))
+        pk.tau_1, msm_v1 = self._msm_dev(pk.tau_1, 1, res.v.ptr, min(n, len(pk.tau_1)))
+        pk.tau_2, msm_v2 = self._msm_dev(pk.tau_2, 2, res.v.ptr, min(n, len(pk.tau_2)))
+        pk.target_1, HZ = self._msm_dev(pk.target_1, 1, res.h.ptr, min(n, len(pk.target_1)))
+        if n_priv > 0:
+            pk.kdelta_1, sum_delta_witness = self._msm_dev(pk.kdelta_1, 1, res.witness.ptr + 32 * n_pub, n_priv)
+        else:
+            sum_delta_witness = self.E.G1() * 0
+
+        A = msm_u + pk.alpha_1 + pk.delta_1 * r
+        B1 = msm_v1 + pk.beta_1 + pk.delta_1 * s
+        B2 = msm_v2 + pk.beta_2 + pk.delta_2 * s
+        C = HZ + sum_delta_witness + A * s + B1 * r + (-pk.delta_1) * (r * s % q)
+        for buf in (res.u, res.v, res.h, res.witness):
+            buf.free()
+        return Proof(A, B2, C)
+
+    # ------------------------------------------------------------------------------------------
+    def verify(self, proof: Proof, public_witness: list) -> bool:
+        assert self.verifying_key, "VerifyingKey has not been generated"
+        vk = self.verifying_key
+        assert len(vk.ic) == len(public_witness), "Length of IC and public_witness must be equal"
+        if isinstance(public_witness, np.ndarray):
+            public_witness = N.limbs_to_ints(public_witness)
+        sum_gamma_witness = self.E.multiexp(vk.ic, public_witness)
+        # e(A, B) == e(alpha, beta) * e(sum_gamma_witness, gamma) * e(C, delta)
+        lhs = self.E.pairing(proof.A, proof.B)
+        rhs = self.E.multi_pairing([vk.alpha_1, sum_gamma_witness, proof.C], [vk.beta_2, vk.gamma_2, vk.delta_2])
+        return lhs == rhs

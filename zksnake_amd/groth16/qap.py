@@ -1,0 +1,103 @@
+"""
+QAP witness evaluation (reference python/zksnake/groth16/qap.py:11-71) on the GPU.
+
+The reference computes, through ~25 Python<->Rust crossings,
+    a, b, c = A.w, B.w, C.w ; u, v, w = ifft(a), ifft(b), ifft(c)
+    uv = ifft(fft(u) * fft(v)) over the doubled domain ; h = (uv - w) / (X^n - 1), remainder must be 0.
+Here the witness goes up once, three CSR mat-vecs (zk_spmv_dev) produce a, b, c in HBM, and
+zk_qap_h_dev runs the whole transform chain without leaving the device.  `evaluate_witness`
+keeps the reference's return shape (four Polynomial objects); the prover uses the device-resident form.
+"""
+
+import numpy as np
+
+from .. import _native as N
+from ..constant import BN254_SCALAR_FIELD
+from ..device import DeviceBuffer
+from ..polynomial import POLY_OBJECT
+from ..utils import next_power_of_two
+
+
+class DeviceQapResult:
+    """u, v, h coefficient vectors (n canonical Fr elements each) living in HBM"""
+
+    def __init__(self, n, u, v, h, witness):
+        self.n = n
+        self.u = u
+        self.v = v
+        self.h = h
+        self.witness = witness  # full witness vector on the device (n_col elements)
+
+
+class QAP:
+    def __init__(self, p=None):
+        self.a = []
+        self.b = []
+        self.c = []
+        self.n_public = 0
+        self.p = p or BN254_SCALAR_FIELD
+        self._dev = None
+
+    def from_r1cs(self, r1cs):
+        assert r1cs.A is not None, "R1CS is not compiled"
+        self.n_public = r1cs.n_public
+        n = next_power_of_two(r1cs.A.n_row)
+        self.a, self.b, self.c = r1cs.A, r1cs.B, r1cs.C
+        self.a.n_row = self.b.n_row = self.c.n_row = n
+        for m in (self.a, self.b, self.c):
+            m._csr = None
+        self._dev = None
+
+    # ---- device-resident evaluation -----------------------------------------------------------
+    def _curve_id(self):
+        return POLY_OBJECT[self.p].curve_id
+
+    def _device_matrices(self):
+        if self._dev is None:
+            mats = []
+            for m in (self.a, self.b, self.c):
+                row_ptr, cols, vals = m.to_csr()
+                mats.append((DeviceBuffer.from_numpy(row_ptr), DeviceBuffer.from_numpy(cols), DeviceBuffer.from_numpy(vals)))
+            self._dev = mats
+        return self._dev
+
+    def evaluate_witness_device(self, witness) -> DeviceQapResult:
+        """witness: list of ints or (n_col, 4) uint64 limbs.  Raises ValueError when the witness does
+        not satisfy the constraints (non-zero remainder), like the reference."""
+        lib = N.ensure_gpu()
+        cid = self._curve_id()
+        n = self.a.n_row
+        if n < 2:
+            raise ValueError("the QAP needs at least 2 rows")
+        log_n = n.bit_length() - 1
+        w_limbs = witness if isinstance(witness, np.ndarray) else N.ints_to_limbs(witness, 4, self.p)
+        if w_limbs.shape[0] != self.a.n_col:
+            raise ValueError("witness length does not match the number of R1CS columns")
+        d_w = DeviceBuffer.from_numpy(w_limbs)
+        eb = 32
+        d_a, d_b, d_c = DeviceBuffer(n * eb), DeviceBuffer(n * eb), DeviceBuffer(n * eb)
+        for (rp, cl, vl), dst in zip(self._device_matrices(), (d_a, d_b, d_c)):
+            N.check(lib.zk_spmv_dev(cid, n, rp.ptr, cl.ptr, vl.ptr, d_w.ptr, dst.ptr, None))
+        d_h = DeviceBuffer(n * eb)
+        d_work = DeviceBuffer(4 * n * eb)
+        ok = N._i(0)
+        N.check(lib.zk_qap_h_dev(cid, log_n, d_a.ptr, d_b.ptr, d_c.ptr, d_h.ptr, d_work.ptr, ok, None))
+        d_work.free()
+        d_c.free()
+        if not ok.value:
+            raise ValueError("(U * V - W) did not divided by Z to zero")
+        return DeviceQapResult(n, d_a, d_b, d_h, d_w)
+
+    # ---- reference-shaped API ---------------------------------------------------------------------
+    def evaluate_witness(self, witness: list):
+        """returns the polynomials (U, V, W, H) like the reference (W is recomputed from C.w)."""
+        mod = POLY_OBJECT[self.p]
+        res = self.evaluate_witness_device(witness)
+        n = res.n
+        u = N.limbs_to_ints(res.u.download((n, 4)))
+        v = N.limbs_to_ints(res.v.download((n, 4)))
+        h = N.limbs_to_ints(res.h.download((n, 4)))
+        w_ints = witness if not isinstance(witness, np.ndarray) else N.limbs_to_ints(witness)
+        w = mod.ifft(self.c.dot(w_ints), n)
+        mk = lambda coeffs: mod.Polynomial(1, [(c, ()) for c in coeffs], n)  # noqa: E731
+        return mk(u), mk(v), mk(w), mk(h)

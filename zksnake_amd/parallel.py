@@ -1,0 +1,49 @@
+"""
+Multi-GPU sharding of one MSM (north star): the windows of the signed-digit
+decomposition are split over the ranks, every rank reduces its windows to ONE partial point
+(already weighted by 2^(c*w)), and the partials are exchanged with an all_gather -- EC addition is
+not a reduction operator of RCCL, so the "sum" is gather + local point additions.
+The payload is one affine point per rank (64..192 bytes).
+"""
+
+import numpy as np
+
+from . import _native as N
+
+
+def window_ranges(n_windows, world):
+    """contiguous, balanced split: [(first, count)] per rank (count may be 0 when world > n_windows)"""
+    base, extra = divmod(n_windows, world)
+    out, first = [], 0
+    for rank in range(world):
+        count = base + (1 if rank < extra else 0)
+        out.append((first, count))
+        first += count
+    return out
+
+
+def sum_points(curve_id, group, partials):
+    """host sum of affine points given as uint64 limb arrays"""
+    lib = N.load()
+    acc = np.zeros(N.point_limbs(curve_id, group), dtype=np.uint64)
+    for part in partials:
+        part = np.ascontiguousarray(part, dtype=np.uint64)
+        nxt = np.zeros_like(acc)
+        N.check(lib.zk_point_add(curve_id, group, N.u64p(acc), N.u64p(part), N.u64p(nxt)))
+        acc = nxt
+    return acc
+
+
+def all_gather_sum(curve_id, group, partial, device=None):
+    """all ranks contribute one partial point (uint64 limbs) and receive the total.
+    Uses the default torch.distributed process group (RCCL on GPUs, gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    mine = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).view(np.int64))
+    if device is not None:
+        mine = mine.to(device)
+    bucket = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(bucket, mine)
+    return sum_points(curve_id, group, [t.cpu().numpy().view(np.uint64) for t in bucket])
