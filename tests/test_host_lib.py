@@ -1,0 +1,129 @@
+"""CPU: the C-ABI shared library loads, exports every symbol include/zkmi.h declares, and its host-side
+functions (single-point arithmetic, codecs, scalar helpers) agree with the oracle.  No GPU compute."""
+
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+from oracle import corc, pyref as R
+from zksnake_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CURVES = (("BN254", 0), ("BLS12_381", 1))
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    with open(os.path.join(ROOT, "include", "zkmi.h")) as f:
+        text = f.read()
+    declared = set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/zkmi.h but not exported by libzkmi.so"
+    assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
+    assert lib.zk_version().startswith(b"zkmi")
+
+
+def test_sizes(lib):
+    assert [lib.zk_fq_limbs(c) for c in (0, 1, 2)] == [4, 6, -1]
+    assert [lib.zk_point_limbs(0, 1), lib.zk_point_limbs(0, 2), lib.zk_point_limbs(1, 1), lib.zk_point_limbs(1, 2)] == [8, 16, 12, 24]
+    assert [lib.zk_point_bytes(0, 1), lib.zk_point_bytes(0, 2), lib.zk_point_bytes(1, 1), lib.zk_point_bytes(1, 2)] == [32, 64, 48, 96]
+
+
+def test_no_gpu_fails_loudly(lib):
+    """without a GPU the compute entry points must report ZK_ERR_HIP, never fall back to the CPU"""
+    if lib.zk_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    assert lib.zk_init(0) == N.ZK_ERR_HIP
+    assert b"no CPU fallback" in lib.zk_last_error()
+    a = np.zeros((4, 4), dtype=np.uint64)
+    out = np.zeros((4, 4), dtype=np.uint64)
+    assert lib.zk_ntt(0, 0, 0, 4, N.u64p(a), 4, N.u64p(out)) == N.ZK_ERR_HIP
+    bases = np.zeros((4, 8), dtype=np.uint64)
+    res = np.zeros(8, dtype=np.uint64)
+    assert lib.zk_msm(0, 1, 4, 4, N.u64p(a), N.u64p(bases), N.u64p(res)) == N.ZK_ERR_HIP
+    with pytest.raises(N.ZkError):
+        N.ensure_gpu()
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+@pytest.mark.parametrize("grp", [1, 2])
+def test_point_arithmetic_and_codec(lib, name, cid, grp):
+    cv = R.curve_by_name(name)
+    g = R.Group(cv, grp)
+    rnd = random.Random(5)
+    W = N.point_limbs(cid, grp)
+    gen = np.zeros(W, dtype=np.uint64)
+    N.check(lib.zk_point_generator(cid, grp, N.u64p(gen)))
+    assert corc.limbs_to_points(gen, cid, grp)[0] == g.gen and lib.zk_point_on_curve(cid, grp, N.u64p(gen)) == 1
+    pts = []
+    for k in [0, 1, 2, cv.r - 1, cv.r, cv.r + 5] + [rnd.randrange(cv.r) for _ in range(4)]:
+        out = np.zeros(W, dtype=np.uint64)
+        N.check(lib.zk_point_mul(cid, grp, N.u64p(gen), N.u64p(N.ints_to_limbs([k])), N.u64p(out)))
+        P = corc.limbs_to_points(out, cid, grp)[0]
+        assert P == g.mul(g.gen, k)
+        pts.append((out, P))
+    nb = lib.zk_point_bytes(cid, grp)
+    for a, Pa in pts:
+        for b, Pb in pts[:5]:
+            out = np.zeros(W, dtype=np.uint64)
+            N.check(lib.zk_point_add(cid, grp, N.u64p(a), N.u64p(b), N.u64p(out)))
+            assert corc.limbs_to_points(out, cid, grp)[0] == g.add(Pa, Pb)
+        buf = np.zeros(nb, dtype=np.uint8)
+        N.check(lib.zk_point_compress(cid, grp, N.u64p(a), N.u8p(buf)))
+        assert bytes(buf) == R.compress(cv, grp, Pa)
+        back = np.zeros(W, dtype=np.uint64)
+        N.check(lib.zk_point_decompress(cid, grp, N.u8p(buf), N.u64p(back)))
+        assert (back == a).all()
+        neg = np.zeros(W, dtype=np.uint64)
+        N.check(lib.zk_point_neg(cid, grp, N.u64p(a), N.u64p(neg)))
+        assert corc.limbs_to_points(neg, cid, grp)[0] == g.neg(Pa)
+    # rejected encodings: bad flags, x off the curve
+    back = np.zeros(W, dtype=np.uint64)
+    bad = np.frombuffer(bytes([0xFF] * nb), dtype=np.uint8).copy()
+    assert lib.zk_point_decompress(cid, grp, N.u8p(bad), N.u64p(back)) == N.ZK_ERR_POINT
+    off = np.zeros(W, dtype=np.uint64)
+    off[0] = 5
+    assert lib.zk_point_on_curve(cid, grp, N.u64p(off)) == 0
+
+
+def test_golden_encodings(lib):
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_vectors.json")) as f:
+        gold = json.load(f)
+    for name, cid in CURVES:
+        for grp in (1, 2):
+            og = gold[name][f"g{grp}"]
+            W = N.point_limbs(cid, grp)
+            nb = lib.zk_point_bytes(cid, grp)
+            gen = np.zeros(W, dtype=np.uint64)
+            N.check(lib.zk_point_generator(cid, grp, N.u64p(gen)))
+            buf = np.zeros(nb, dtype=np.uint8)
+            N.check(lib.zk_point_compress(cid, grp, N.u64p(gen), N.u8p(buf)))
+            assert bytes(buf).hex() == og["generator_compressed"]
+            N.check(lib.zk_point_compress(cid, grp, N.u64p(np.zeros(W, dtype=np.uint64)), N.u8p(buf)))
+            assert bytes(buf).hex() == og["infinity_compressed"]
+            # dlog * G compresses to the recorded MSM result
+            out = np.zeros(W, dtype=np.uint64)
+            N.check(lib.zk_point_mul(cid, grp, N.u64p(gen), N.u64p(N.ints_to_limbs([int(og["msm_dlog"])])), N.u64p(out)))
+            N.check(lib.zk_point_compress(cid, grp, N.u64p(out), N.u8p(buf)))
+            assert bytes(buf).hex() == og["msm_compressed"]
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+def test_scalar_field_helpers(lib, name, cid):
+    cv = R.curve_by_name(name)
+    rnd = random.Random(6)
+    for n in (1, 2, 8, 64, 1 << 20):
+        out = np.zeros(4, dtype=np.uint64)
+        N.check(lib.zk_fr_root_of_unity(cid, n, N.u64p(out)))
+        assert N.limbs_to_ints(out.reshape(1, 4))[0] == cv.root_of_unity(n)
+    for n in (1, 2, 8, 64):
+        for tau in (rnd.randrange(cv.r), cv.root_of_unity(n) if n > 1 else 1, 1, cv.r + 3):
+            o = np.zeros((n, 4), dtype=np.uint64)
+            N.check(lib.zk_fr_lagrange_coeffs(cid, n, N.u64p(N.ints_to_limbs([tau])), N.u64p(o)))
+            assert N.limbs_to_ints(o) == R.lagrange_at(n, tau % cv.r, cv)
+    out = np.zeros(4, dtype=np.uint64)
+    assert lib.zk_fr_root_of_unity(cid, 1 << 40, N.u64p(out)) == N.ZK_ERR_DOMAIN
