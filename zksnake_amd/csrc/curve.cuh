@@ -117,6 +117,61 @@ ZK_HD void xyzz_add_affine(XYZZ<F>& acc, const Affine<F>& q) {
     acc.ZZZ = F::mul(acc.ZZZ, PPP);
 }
 
+#if defined(__HIPCC__)
+// Device form used by the MSM inner loop: the affine operand is read from memory (16-byte vector loads of
+// the packed Montgomery row) and dies right after U2/S2, so it does not occupy registers across the ten
+// field multiplications; the (rare) doubling case simply reads it again.
+template <class F>
+__device__ __forceinline__ Affine<F> load_affine_row(const uint32_t* p) {
+    Affine<F> a;
+    uint32_t* d = reinterpret_cast<uint32_t*>(&a);
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 2 * F::LIMBS / 4; ++i) {
+        uint4 t = q[i];
+        d[4 * i] = t.x; d[4 * i + 1] = t.y; d[4 * i + 2] = t.z; d[4 * i + 3] = t.w;
+    }
+    return a;
+}
+
+template <class F>
+__device__ __forceinline__ void xyzz_add_affine_mem(XYZZ<F>& acc, const uint32_t* src, bool negate) {
+    typedef typename F::T T;
+    T U2, S2;
+    {
+        Affine<F> q = load_affine_row<F>(src);
+        if (aff_is_inf<F>(q)) return;
+        if (negate) q.y = F::neg(q.y);
+        if (xyzz_is_inf<F>(acc)) {
+            acc = {q.x, q.y, F::one(), F::one()};
+            return;
+        }
+        U2 = F::mul(q.x, acc.ZZ);
+        S2 = F::mul(q.y, acc.ZZZ);
+    }
+    T Pd = F::sub(U2, acc.X);
+    T R = F::sub(S2, acc.Y);
+    if (F::is_zero(Pd)) {
+        if (F::is_zero(R)) {
+            Affine<F> q = load_affine_row<F>(src);
+            if (negate) q.y = F::neg(q.y);
+            acc = xyzz_dbl_affine<F>(q);
+        } else {
+            acc = xyzz_inf<F>();
+        }
+        return;
+    }
+    T PP = F::sqr(Pd);
+    T PPP = F::mul(Pd, PP);
+    T Q = F::mul(acc.X, PP);
+    T X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+    acc.Y = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(acc.Y, PPP));
+    acc.X = X3;
+    acc.ZZ = F::mul(acc.ZZ, PP);
+    acc.ZZZ = F::mul(acc.ZZZ, PPP);
+}
+#endif
+
 // acc + q, both XYZZ (add-2008-s): 12M + 2S
 template <class F>
 ZK_HD XYZZ<F> xyzz_add(const XYZZ<F>& p, const XYZZ<F>& q) {

@@ -150,8 +150,8 @@ __global__ __launch_bounds__(SORT_THREADS) void hist_kernel(const uint16_t* __re
 }
 
 // per bucket key: exclusive prefix over the sub-histograms of its group, total, segment count
-__global__ void prefix_kernel(uint32_t* __restrict__ hist, int group_size, uint32_t B, uint32_t n_keys, uint32_t seg_len,
-                              uint32_t* __restrict__ total, uint32_t* __restrict__ nseg) {
+__global__ void prefix_kernel(uint32_t* __restrict__ hist, int group_size, uint32_t B, uint32_t n_keys,
+                              uint32_t* __restrict__ total) {
     uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= n_keys) return;
     uint32_t g = key / B, b = key % B;
@@ -163,7 +163,17 @@ __global__ void prefix_kernel(uint32_t* __restrict__ hist, int group_size, uint3
         run += t;
     }
     total[key] = run;
-    nseg[key] = (run + seg_len - 1) / seg_len;
+}
+
+// The sorted entry list is cut into uniform segments of seg_len entries (one lane each), whatever the bucket
+// sizes are.  A "run" is the part of one bucket inside one segment; bucket `key` owns
+//   nruns = 1 + (last_entry / seg_len) - (first_entry / seg_len)   consecutive partial slots.
+__global__ void runs_kernel(const uint32_t* __restrict__ bucket_start, uint32_t n_keys, uint32_t seg_len,
+                            uint32_t* __restrict__ nruns) {
+    uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= n_keys) return;
+    uint32_t s0 = bucket_start[key], s1 = bucket_start[key + 1];
+    nruns[key] = s1 > s0 ? 1 + (s1 - 1) / seg_len - s0 / seg_len : 0;
 }
 
 // two-level exclusive scan: blocks of 1024
@@ -246,32 +256,41 @@ template <class G>
 __global__ __launch_bounds__(256) void accumulate_kernel(const uint32_t* __restrict__ bases,
                                                          const uint32_t* __restrict__ sorted,
                                                          const uint32_t* __restrict__ bucket_start,
-                                                         const uint32_t* __restrict__ seg_start, uint32_t n_keys,
+                                                         const uint32_t* __restrict__ run_start, uint32_t n_keys,
                                                          uint32_t seg_len, uint32_t* __restrict__ partials) {
     typedef typename G::F F;
     constexpr int AW = 2 * F::LIMBS;
-    uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_seg = seg_start[n_keys];
-    if (seg >= n_seg) return;
-    // largest key with seg_start[key] <= seg
+    constexpr int XW = 4 * F::LIMBS;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = bucket_start[n_keys];
+    const uint32_t begin = t * seg_len;
+    if (begin >= total) return;
+    uint32_t end = begin + seg_len;
+    if (end > total) end = total;
+    // bucket of the first entry: largest key with bucket_start[key] <= begin (its end is > begin)
     uint32_t lo = 0, hi = n_keys;
     while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
-        if (seg_start[mid] <= seg) lo = mid; else hi = mid;
+        if (bucket_start[mid] <= begin) lo = mid; else hi = mid;
     }
     uint32_t key = lo;
-    uint32_t j = seg - seg_start[key];
-    uint32_t begin = bucket_start[key] + j * seg_len;
-    uint32_t end = bucket_start[key + 1];
-    if (end > begin + seg_len) end = begin + seg_len;
+    uint32_t next = bucket_start[key + 1];
     XYZZ<F> acc = xyzz_inf<F>();
     for (uint32_t e = begin; e < end; ++e) {
+        if (e == next) {
+            // the bucket ends inside this segment: flush its run, move to the next non-empty bucket
+            store_xyzz<F>(partials + (size_t)(run_start[key] + t - bucket_start[key] / seg_len) * XW, acc);
+            acc = xyzz_inf<F>();
+            do {
+                ++key;
+                next = bucket_start[key + 1];
+            } while (next <= e);
+        }
         uint32_t ref = sorted[e];
-        Affine<F> p = load_affine<F>(bases + (size_t)(ref & 0x7FFFFFFFu) * AW);
-        if (ref & 0x80000000u) p.y = F::neg(p.y);
-        xyzz_add_affine<F>(acc, p);
+        const uint32_t* src = bases + (size_t)(ref & 0x7FFFFFFFu) * AW;
+        xyzz_add_affine_mem<F>(acc, src, (ref >> 31) != 0);
     }
-    store_xyzz<F>(partials + (size_t)seg * 4 * F::LIMBS, acc);
+    store_xyzz<F>(partials + (size_t)(run_start[key] + t - bucket_start[key] / seg_len) * XW, acc);
 }
 
 // ---- 6. combine ---------------------------------------------------------------------------------
@@ -293,41 +312,55 @@ __global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict
 
 // ---- 7. bucket reduction ----------------------------------------------------------------------------
 
-// out[o] = sum_{j < count} in[(o / per_group) * group_stride + (o % per_group) * outer + j * inner]
+// Two strided sums in one launch (rows and columns run side by side: the stage is latency-bound, few waves):
+//   out[o] = sum_{j < count} in[(o / per_group) * group_stride + (o % per_group) * outer + j * inner]
 // one wave per output element; lanes stride over j, then a 6-level shuffle tree.
+struct SumJob {
+    uint32_t n_out, per_group, group_stride, outer, inner, count;
+    uint32_t out_offset;  // in points, into the shared output array
+};
+
 template <class G>
 __global__ __launch_bounds__(256) void strided_sum_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                          uint32_t n_out, uint32_t per_group, uint32_t group_stride,
-                                                          uint32_t outer, uint32_t inner, uint32_t count) {
+                                                          SumJob j0, SumJob j1) {
     typedef typename G::F F;
     constexpr int XW = 4 * F::LIMBS;
     uint32_t o = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t lane = threadIdx.x & 63;
-    if (o >= n_out) return;  // whole wave exits together
-    size_t base = (size_t)(o / per_group) * group_stride + (size_t)(o % per_group) * outer;
+    SumJob job = j0;
+    if (o >= j0.n_out) {
+        o -= j0.n_out;
+        job = j1;
+    }
+    if (o >= job.n_out) return;  // whole wave exits together
+    size_t base = (size_t)(o / job.per_group) * job.group_stride + (size_t)(o % job.per_group) * job.outer;
     XYZZ<F> acc = xyzz_inf<F>();
-    for (uint32_t j = lane; j < count; j += 64) {
-        XYZZ<F> p = load_xyzz<F>(in + (base + (size_t)j * inner) * XW);
+    for (uint32_t j = lane; j < job.count; j += 64) {
+        XYZZ<F> p = load_xyzz<F>(in + (base + (size_t)j * job.inner) * XW);
         acc = xyzz_add<F>(acc, p);
     }
     for (int m = 32; m >= 1; m >>= 1) {
         XYZZ<F> other = shfl_xor_xyzz<F>(acc, m);
         acc = xyzz_add<F>(acc, other);
     }
-    if (lane == 0) store_xyzz<F>(out + (size_t)o * XW, acc);
+    if (lane == 0) store_xyzz<F>(out + ((size_t)job.out_offset + o) * XW, acc);
 }
 
 // one workgroup per array of m <= 256 points: S = sum_j j * X_j and T = sum_j X_j
 // via an inclusive suffix scan (log m steps) followed by a tree sum of the suffixes 1..m-1.
+// Blocks [0, n0) take arrays of m0 points from in0, blocks [n0, ..) arrays of m1 points from in1.
 constexpr int HS_THREADS = 256;
 template <class G>
-__global__ __launch_bounds__(HS_THREADS) void weighted_sum_kernel(const uint32_t* __restrict__ in, uint32_t m,
+__global__ __launch_bounds__(HS_THREADS) void weighted_sum_kernel(const uint32_t* __restrict__ in0, uint32_t m0, uint32_t n0,
+                                                                  const uint32_t* __restrict__ in1, uint32_t m1,
                                                                   uint32_t* __restrict__ out) {
     typedef typename G::F F;
     constexpr int XW = 4 * F::LIMBS;
     __shared__ uint32_t sh[HS_THREADS * XW];
     const uint32_t j = threadIdx.x;
-    const uint32_t* arr = in + (size_t)blockIdx.x * m * XW;
+    const bool first = blockIdx.x < n0;
+    const uint32_t m = first ? m0 : m1;
+    const uint32_t* arr = first ? in0 + (size_t)blockIdx.x * m0 * XW : in1 + (size_t)(blockIdx.x - n0) * m1 * XW;
     XYZZ<F> v = j < m ? load_xyzz<F>(arr + (size_t)j * XW) : xyzz_inf<F>();
     for (uint32_t off = 1; off < m; off <<= 1) {
         store_xyzz<F>(sh + (size_t)j * XW, v);
@@ -341,7 +374,9 @@ __global__ __launch_bounds__(HS_THREADS) void weighted_sum_kernel(const uint32_t
     // v = suffix sum s_j
     if (j == 0) store_xyzz<F>(out + ((size_t)blockIdx.x * 2 + 1) * XW, v);  // T = s_0
     if (j == 0 || j >= m) v = xyzz_inf<F>();
-    for (uint32_t off = HS_THREADS / 2; off >= 1; off >>= 1) {
+    uint32_t top = 1;
+    while (top < m) top <<= 1;
+    for (uint32_t off = top / 2; off >= 1; off >>= 1) {
         store_xyzz<F>(sh + (size_t)j * XW, v);
         __syncthreads();
         if (j < off) {
@@ -510,8 +545,7 @@ struct MsmPlan : MsmPlanBase {
         ZK_HIP(hipMalloc(&d_sorted, entries * 4));
         ZK_HIP(hipMalloc(&d_partials, (size_t)max_segs * XW * 4));
         ZK_HIP(hipMalloc(&d_buckets, n_keys * XW * 4));
-        ZK_HIP(hipMalloc(&d_rows, (size_t)nwin * R * XW * 4));
-        ZK_HIP(hipMalloc(&d_cols, (size_t)nwin * C * XW * 4));
+        ZK_HIP(hipMalloc(&d_rows, (size_t)nwin * (R + C) * XW * 4));
         ZK_HIP(hipMalloc(&d_final, (size_t)nwin * 4 * XW * 4));
         ZK_HIP(hipHostMalloc(&h_final, (size_t)nwin * 4 * XW * 4));
         for (auto& e : ev) ZK_HIP(hipEventCreate(&e));
@@ -561,25 +595,28 @@ struct MsmPlan : MsmPlanBase {
             // 2. histogram
             hipLaunchKernelGGL(hist_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), B * 4, st, d_dig, m, c, w_first, nchunk, ch_len, d_hist);
             // 3. prefix + scans
-            hipLaunchKernelGGL(prefix_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_hist, nchunk, B, n_keys, seg_len, d_total, d_nseg);
+            hipLaunchKernelGGL(prefix_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_hist, nchunk, B, n_keys, d_total);
             int rc;
             if ((rc = exclusive_scan(d_total, n_keys, d_bstart, st))) return rc;
+            hipLaunchKernelGGL(runs_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_bstart, n_keys, seg_len, d_nseg);
             if ((rc = exclusive_scan(d_nseg, n_keys, d_sstart, st))) return rc;
             // 4. scatter
             hipLaunchKernelGGL(scatter_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), B * 4, st, d_dig, m, c, w_first, nchunk, ch_len, 0, d_hist, d_bstart, d_sorted);
             ZK_HIP(hipEventRecord(ev[1], st));
             // 5. accumulate
-            uint64_t seg_bound = (uint64_t)w_count * m / seg_len + n_keys + 1;
-            hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((seg_bound + 255) / 256)), dim3(256), 0, st, d_bases, d_sorted, d_bstart, d_sstart, n_keys, seg_len, d_partials);
+            uint64_t lanes = ((uint64_t)w_count * m + seg_len - 1) / seg_len;
+            hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, d_bases, d_sorted, d_bstart, d_sstart, n_keys, seg_len, d_partials);
             ZK_HIP(hipEventRecord(ev[2], st));
             // 6. combine
             hipLaunchKernelGGL(combine_kernel<G>, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_partials, d_sstart, n_keys, d_buckets);
             // 7. reduce: rows (sum over lo), cols (sum over hi), weighted sums
             uint32_t n_rows = (uint32_t)w_count * R, n_cols = (uint32_t)w_count * C;
-            hipLaunchKernelGGL(strided_sum_kernel<G>, dim3((n_rows * 64 + 255) / 256), dim3(256), 0, st, d_buckets, d_rows, n_rows, R, B, C, 1u, C);
-            hipLaunchKernelGGL(strided_sum_kernel<G>, dim3((n_cols * 64 + 255) / 256), dim3(256), 0, st, d_buckets, d_cols, n_cols, C, B, 1u, C, R);
-            hipLaunchKernelGGL(weighted_sum_kernel<G>, dim3(w_count), dim3(HS_THREADS), 0, st, d_rows, R, d_final);
-            hipLaunchKernelGGL(weighted_sum_kernel<G>, dim3(w_count), dim3(HS_THREADS), 0, st, d_cols, C, d_final + (size_t)w_count * 2 * XW);
+            SumJob rows = {n_rows, R, B, C, 1u, C, 0u};
+            SumJob cols = {n_cols, C, B, 1u, C, R, n_rows};
+            // d_rows holds the row sums followed by the column sums
+            hipLaunchKernelGGL(strided_sum_kernel<G>, dim3(((n_rows + n_cols) * 64 + 255) / 256), dim3(256), 0, st, d_buckets, d_rows, rows, cols);
+            hipLaunchKernelGGL(weighted_sum_kernel<G>, dim3(2 * w_count), dim3(HS_THREADS), 0, st, d_rows, R, (uint32_t)w_count,
+                               d_rows + (size_t)n_rows * XW, C, d_final);
             ZK_HIP(hipGetLastError());
             ZK_HIP(hipMemcpyAsync(h_final, d_final, (size_t)w_count * 4 * XW * 4, hipMemcpyDeviceToHost, st));
             ZK_HIP(hipEventRecord(ev[3], st));
