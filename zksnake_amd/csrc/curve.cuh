@@ -123,15 +123,14 @@ ZK_HD void xyzz_add_affine(XYZZ<F>& acc, const Affine<F>& q) {
 // field multiplications; the (rare) doubling case simply reads it again.
 template <class F>
 __device__ __forceinline__ Affine<F> load_affine_row(const uint32_t* p) {
-    Affine<F> a;
-    uint32_t* d = reinterpret_cast<uint32_t*>(&a);
+    uint32_t w[2 * F::LIMBS];
     const uint4* q = reinterpret_cast<const uint4*>(p);
 #pragma unroll
     for (int i = 0; i < 2 * F::LIMBS / 4; ++i) {
         uint4 t = q[i];
-        d[4 * i] = t.x; d[4 * i + 1] = t.y; d[4 * i + 2] = t.z; d[4 * i + 3] = t.w;
+        w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
     }
-    return a;
+    return {F::load(w), F::load(w + F::LIMBS)};
 }
 
 template <class F>

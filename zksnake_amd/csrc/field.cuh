@@ -1,14 +1,22 @@
-// field.cuh -- prime-field arithmetic for the zksnake hot path on gfx950 (and the host side of
-// the same library).  32-bit limbs, Montgomery form, R = 2^(32 N).
+// field.cuh -- prime-field arithmetic for the zksnake hot path on gfx950 (and the host side of the same
+// library): 29-bit limbs, Montgomery form with R = 2^(29 N), values kept semi-reduced in [0, 2p).
 //
 // Replaces what the reference gets from ark-ff 0.4.2 `Fp<MontBackend<..>, N>` behind
-// src/bn254/{curve,polynomial}.rs and src/bls12_381/{curve,polynomial}.rs (the crates are not
-// vendored in /root/reference; the algorithm here is textbook CIOS Montgomery multiplication).
+// src/bn254/{curve,polynomial}.rs and src/bls12_381/{curve,polynomial}.rs (the crates are not vendored in
+// /root/reference; Montgomery multiplication is textbook).
 //
-// CDNA4 notes: the only wide integer multiplier is v_mad_u64_u32 (32x32+64 -> 64); every
-// partial product below is written as `(uint64_t)a * b + c` so hipcc selects it.  All loops
-// are fully unrolled over compile-time limb counts and the modulus limbs are constexpr, so
-// they become literals / SGPRs instead of VGPRs.
+// Why 29-bit limbs on CDNA4 (measured, profiles/r01_ubench_valu.log and DESIGN.md section 4):
+//   v_mad_u64_u32 (32x32+64 -> 64) costs ~6 cycles per wave, a plain integer op ~4, and there is no
+//   carry-in multiply-add.  With full 32-bit limbs every partial product needs two extra add/mov
+//   instructions to thread carries (a 254-bit product took ~1900 cycles/wave, only 40 % of it in the
+//   128 multiply-adds).  With 29-bit limbs a 64-bit column accumulator absorbs all 2N partial products
+//   of a column (2 * 14 * 2^58 < 2^64) with NO carry handling: the product is N^2 + N^2 + N bare
+//   v_mad_u64_u32 plus one shift/mask per column -- ~1100 cycles/wave (1.8x), and 2.8x for a lone wave,
+//   which is what the latency-bound reduction stages see.
+//   The spare bits (R / p >= 70) also remove every conditional subtraction from the product:
+//   inputs < 2p give an output < 2p.
+//
+// Memory / ABI form of an element: W little-endian 32-bit words (8 or 12); `fp_unpack` / `fp_pack` convert.
 #pragma once
 #include <cstdint>
 #include "field_params.h"
@@ -30,6 +38,10 @@
 
 namespace zkmi {
 
+constexpr int LIMB_BITS = 29;
+constexpr uint32_t LIMB_MASK = (1u << LIMB_BITS) - 1;
+
+// N limbs of 29 bits (the top limb may be shorter), normalized, value in [0, 2p)
 template <class P>
 struct Fp {
     static constexpr int N = P::N;
@@ -37,21 +49,13 @@ struct Fp {
     uint32_t v[P::N];
 };
 
-// ---- helpers --------------------------------------------------------------------------
+// ---- constants / predicates ---------------------------------------------------------------------
 
 template <class P>
 ZK_HD Fp<P> fp_zero() {
     Fp<P> r;
 #pragma unroll
     for (int i = 0; i < P::N; ++i) r.v[i] = 0;
-    return r;
-}
-
-template <class P>
-ZK_HD Fp<P> fp_one() {
-    Fp<P> r;
-#pragma unroll
-    for (int i = 0; i < P::N; ++i) r.v[i] = P::ONE[i];
     return r;
 }
 
@@ -64,94 +68,80 @@ ZK_HD Fp<P> fp_const(const uint32_t (&c)[P::N]) {
 }
 
 template <class P>
+ZK_HD Fp<P> fp_one() {
+    return fp_const<P>(P::ONE);
+}
+
+// zero mod p: the representative is 0 or p
+template <class P>
 ZK_HD bool fp_is_zero(const Fp<P>& a) {
-    uint32_t o = 0;
-#pragma unroll
-    for (int i = 0; i < P::N; ++i) o |= a.v[i];
-    return o == 0;
-}
-
-template <class P>
-ZK_HD bool fp_eq(const Fp<P>& a, const Fp<P>& b) {
-    uint32_t o = 0;
-#pragma unroll
-    for (int i = 0; i < P::N; ++i) o |= a.v[i] ^ b.v[i];
-    return o == 0;
-}
-
-// r = a - p, returns the final borrow (1 when a < p)
-template <class P>
-ZK_HD uint32_t fp_sub_mod_raw(uint32_t* r, const uint32_t* a) {
-    uint64_t borrow = 0;
+    uint32_t z = 0, e = 0;
 #pragma unroll
     for (int i = 0; i < P::N; ++i) {
-        uint64_t t = (uint64_t)a[i] - P::MOD[i] - borrow;
-        r[i] = (uint32_t)t;
-        borrow = (t >> 32) & 1;
+        z |= a.v[i];
+        e |= a.v[i] ^ P::M[i];
     }
-    return (uint32_t)borrow;
+    return z == 0 || e == 0;
 }
 
-// conditional final subtraction: a in [0, 2p) -> [0, p)
-template <class P>
-ZK_HD void fp_reduce_once(Fp<P>& a) {
-    uint32_t t[P::N];
-    uint32_t borrow = fp_sub_mod_raw<P>(t, a.v);
-#pragma unroll
-    for (int i = 0; i < P::N; ++i) a.v[i] = borrow ? a.v[i] : t[i];
-}
+// ---- addition / subtraction: both candidates (x and x -/+ 2p) are carried through one pass of signed
+// carries and the in-range one is selected, so the result is normalized and again in [0, 2p) ------------
 
 template <class P>
 ZK_HD Fp<P> fp_add(const Fp<P>& a, const Fp<P>& b) {
-    Fp<P> r;
-    uint64_t carry = 0;
+    constexpr int N = P::N;
+    Fp<P> s, t;
+    int32_t cs = 0, ct = 0;
 #pragma unroll
-    for (int i = 0; i < P::N; ++i) {
-        uint64_t t = (uint64_t)a.v[i] + b.v[i] + carry;
-        r.v[i] = (uint32_t)t;
-        carry = t >> 32;
+    for (int i = 0; i < N; ++i) {
+        int32_t x = (int32_t)(a.v[i] + b.v[i]);
+        int32_t u = x + cs;
+        int32_t w = x - (int32_t)P::P2[i] + ct;
+        if (i < N - 1) {
+            s.v[i] = (uint32_t)u & LIMB_MASK;
+            cs = u >> LIMB_BITS;
+            t.v[i] = (uint32_t)w & LIMB_MASK;
+            ct = w >> LIMB_BITS;
+        } else {
+            s.v[i] = (uint32_t)u;
+            t.v[i] = (uint32_t)w;
+        }
     }
-    // all four moduli leave at least one spare bit in the top limb, so a + b < 2^(32N)
-    fp_reduce_once<P>(r);
-    return r;
+    const bool below = (int32_t)t.v[N - 1] < 0;  // a + b < 2p
+#pragma unroll
+    for (int i = 0; i < N; ++i) s.v[i] = below ? s.v[i] : t.v[i];
+    return s;
 }
 
 template <class P>
 ZK_HD Fp<P> fp_sub(const Fp<P>& a, const Fp<P>& b) {
-    Fp<P> r;
-    uint64_t borrow = 0;
+    constexpr int N = P::N;
+    Fp<P> s, t;
+    int32_t cs = 0, ct = 0;
 #pragma unroll
-    for (int i = 0; i < P::N; ++i) {
-        uint64_t t = (uint64_t)a.v[i] - b.v[i] - borrow;
-        r.v[i] = (uint32_t)t;
-        borrow = (t >> 32) & 1;
+    for (int i = 0; i < N; ++i) {
+        int32_t x = (int32_t)a.v[i] - (int32_t)b.v[i];
+        int32_t u = x + cs;
+        int32_t w = x + (int32_t)P::P2[i] + ct;
+        if (i < N - 1) {
+            s.v[i] = (uint32_t)u & LIMB_MASK;
+            cs = u >> LIMB_BITS;
+            t.v[i] = (uint32_t)w & LIMB_MASK;
+            ct = w >> LIMB_BITS;
+        } else {
+            s.v[i] = (uint32_t)u;
+            t.v[i] = (uint32_t)w;
+        }
     }
-    uint32_t mask = (uint32_t)0 - (uint32_t)borrow;
-    uint64_t carry = 0;
+    const bool neg = (int32_t)s.v[N - 1] < 0;  // a < b
 #pragma unroll
-    for (int i = 0; i < P::N; ++i) {
-        uint64_t t = (uint64_t)r.v[i] + (P::MOD[i] & mask) + carry;
-        r.v[i] = (uint32_t)t;
-        carry = t >> 32;
-    }
-    return r;
+    for (int i = 0; i < N; ++i) s.v[i] = neg ? t.v[i] : s.v[i];
+    return s;
 }
 
 template <class P>
 ZK_HD Fp<P> fp_neg(const Fp<P>& a) {
-    Fp<P> r;
-    uint32_t nz = 0;
-#pragma unroll
-    for (int i = 0; i < P::N; ++i) nz |= a.v[i];
-    uint32_t mask = nz ? 0xFFFFFFFFu : 0u;
-    uint64_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < P::N; ++i) {
-        uint64_t t = (uint64_t)(P::MOD[i] & mask) - a.v[i] - borrow;
-        r.v[i] = (uint32_t)t;
-        borrow = (t >> 32) & 1;
-    }
-    return r;
+    return fp_sub<P>(fp_zero<P>(), a);
 }
 
 template <class P>
@@ -159,81 +149,192 @@ ZK_HD Fp<P> fp_dbl(const Fp<P>& a) {
     return fp_add<P>(a, a);
 }
 
-// Montgomery product a*b*R^-1 mod p, inputs and output in [0, p).
-// Finely-integrated operand scanning: for each limb of b one pass adds a*b_i and m*p
-// together, so the accumulator never needs more than N+1 limbs.
+template <class P>
+ZK_HD bool fp_eq(const Fp<P>& a, const Fp<P>& b) {
+    return fp_is_zero<P>(fp_sub<P>(a, b));
+}
+
+// ---- Montgomery product a*b*R^-1 mod p: column-wise (product scanning) with the reduction folded into the
+// same columns.  Inputs normalized with (a/p)*(b/p) <= R/p (>= 70 for all four fields), output < 2p. -------
+
 template <class P>
 ZK_MUL Fp<P> fp_mul(const Fp<P> a, const Fp<P> b) {
     constexpr int N = P::N;
-    uint32_t t[N + 1];
+    uint64_t acc = 0;
+    uint32_t m[N];
+    Fp<P> r;
 #pragma unroll
-    for (int i = 0; i <= N; ++i) t[i] = 0;
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P::M[k - i];
+        m[k] = ((uint32_t)acc * P::INV) & LIMB_MASK;
+        acc += (uint64_t)m[k] * P::M[0];
+        acc >>= LIMB_BITS;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; ++k) {
+#pragma unroll
+        for (int i = k - N + 1; i < N; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = k - N + 1; i < N; ++i) acc += (uint64_t)m[i] * P::M[k - i];
+        r.v[k - N] = (uint32_t)acc & LIMB_MASK;
+        acc >>= LIMB_BITS;
+    }
+    r.v[N - 1] = (uint32_t)acc;
+    return r;
+}
+
+// squaring: the cross terms are computed once against pre-doubled limbs (N(N+1)/2 instead of N^2 products)
+template <class P>
+ZK_MUL Fp<P> fp_sqr(const Fp<P> a) {
+    constexpr int N = P::N;
+    uint64_t acc = 0;
+    uint32_t m[N], d[N];
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) d[i] = a.v[i] << 1;
+#pragma unroll
+    for (int k = 0; k < 2 * N - 1; ++k) {
+        const int lo = k < N ? 0 : k - N + 1;
+        const int hi = k < N ? k : N - 1;
+#pragma unroll
+        for (int i = lo; i <= hi; ++i) {
+            const int j = k - i;
+            if (i < j) acc += (uint64_t)d[i] * a.v[j];
+            else if (i == j) acc += (uint64_t)a.v[i] * a.v[i];
+        }
+        if (k < N) {
+#pragma unroll
+            for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P::M[k - i];
+            m[k] = ((uint32_t)acc * P::INV) & LIMB_MASK;
+            acc += (uint64_t)m[k] * P::M[0];
+        } else {
+#pragma unroll
+            for (int i = k - N + 1; i < N; ++i) acc += (uint64_t)m[i] * P::M[k - i];
+            r.v[k - N] = (uint32_t)acc & LIMB_MASK;
+        }
+        acc >>= LIMB_BITS;
+    }
+    r.v[N - 1] = (uint32_t)acc;
+    return r;
+}
+
+// ---- memory form: W 32-bit words <-> N 29-bit limbs ---------------------------------------------------
+
+// any integer below 2^(32 W) -> normalized limbs (no reduction)
+template <class P>
+ZK_HD Fp<P> fp_unpack(const uint32_t* w) {
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        const int bit = LIMB_BITS * i;
+        const int word = bit >> 5, sh = bit & 31;
+        uint32_t x = 0;
+        if (word < P::W) x = w[word] >> sh;
+        if (sh > 32 - LIMB_BITS && word + 1 < P::W) x |= w[word + 1] << (32 - sh);
+        r.v[i] = x & LIMB_MASK;
+    }
+    return r;
+}
+
+// normalized limbs of a value below 2^(32 W) -> words
+template <class P>
+ZK_HD void fp_pack(uint32_t* w, const Fp<P>& a) {
+#pragma unroll
+    for (int j = 0; j < P::W; ++j) {
+        // word j collects bits [32 j, 32 j + 32): limbs whose range overlaps
+        uint32_t x = 0;
+#pragma unroll
+        for (int i = 0; i < P::N; ++i) {
+            const int lo = LIMB_BITS * i;            // first bit of limb i
+            const int rel = lo - 32 * j;             // position of that bit inside word j
+            if (rel > -LIMB_BITS - 3 && rel < 32) {
+                if (rel >= 0) x |= a.v[i] << rel;
+                else if (-rel < 32) x |= a.v[i] >> (-rel);
+            }
+        }
+        w[j] = x;
+    }
+}
+
+// conditional subtraction of p: [0, 2p) -> [0, p)
+template <class P>
+ZK_HD Fp<P> fp_reduce_full(const Fp<P>& a) {
+    constexpr int N = P::N;
+    Fp<P> t;
+    int32_t c = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const uint32_t bi = b.v[i];
-        uint64_t s = (uint64_t)a.v[0] * bi + t[0];
-        const uint32_t m = (uint32_t)s * P::INV;
-        uint64_t r = (uint64_t)m * P::MOD[0] + (uint32_t)s;
-        uint32_t c1 = (uint32_t)(s >> 32);
-        uint32_t c2 = (uint32_t)(r >> 32);
-#pragma unroll
-        for (int j = 1; j < N; ++j) {
-            s = (uint64_t)a.v[j] * bi + t[j] + c1;
-            c1 = (uint32_t)(s >> 32);
-            r = (uint64_t)m * P::MOD[j] + (uint32_t)s + c2;
-            c2 = (uint32_t)(r >> 32);
-            t[j - 1] = (uint32_t)r;
+        int32_t w = (int32_t)a.v[i] - (int32_t)P::M[i] + c;
+        if (i < N - 1) {
+            t.v[i] = (uint32_t)w & LIMB_MASK;
+            c = w >> LIMB_BITS;
+        } else {
+            t.v[i] = (uint32_t)w;
         }
-        uint64_t z = (uint64_t)t[N] + c1 + c2;
-        t[N - 1] = (uint32_t)z;
-        t[N] = (uint32_t)(z >> 32);
     }
-    // t < 2p < 2^(32N): t[N] is zero here
-    Fp<P> out;
+    const bool below = (int32_t)t.v[N - 1] < 0;
 #pragma unroll
-    for (int i = 0; i < N; ++i) out.v[i] = t[i];
-    fp_reduce_once<P>(out);
-    return out;
+    for (int i = 0; i < N; ++i) t.v[i] = below ? a.v[i] : t.v[i];
+    return t;
 }
 
+// canonical integer (any value below 2^(32 W): reduced like Fr::from(BigUint)) -> Montgomery form
 template <class P>
-ZK_HD Fp<P> fp_sqr(const Fp<P>& a) {
-    return fp_mul<P>(a, a);
+ZK_HD Fp<P> fp_from_canonical(const uint32_t* w) {
+    return fp_mul<P>(fp_unpack<P>(w), fp_const<P>(P::R2));
 }
 
-// canonical integer (< 2^(32N), any value) -> Montgomery form
+// Montgomery form -> canonical integer in [0, p) as W words
 template <class P>
-ZK_HD Fp<P> fp_from_canonical(const uint32_t* a) {
-    Fp<P> x;
-#pragma unroll
-    for (int i = 0; i < P::N; ++i) x.v[i] = a[i];
-    // inputs may exceed p (the reference reduces on entry: Fr::from(BigUint)); 2^(32N) < 8p for
-    // every field here except BLS Fr/Fq (< 3p / < 10p): a short subtract loop is enough.
-    for (int k = 0; k < 10; ++k) {
-        uint32_t t[P::N];
-        uint32_t borrow = fp_sub_mod_raw<P>(t, x.v);
-        if (borrow) break;
-#pragma unroll
-        for (int i = 0; i < P::N; ++i) x.v[i] = t[i];
-    }
-    return fp_mul<P>(x, fp_const<P>(P::R2));
-}
-
-template <class P>
-ZK_HD void fp_to_canonical(uint32_t* out, const Fp<P>& a) {
+ZK_HD void fp_to_canonical(uint32_t* w, const Fp<P>& a) {
     Fp<P> o = fp_zero<P>();
     o.v[0] = 1;
-    Fp<P> r = fp_mul<P>(a, o);
-#pragma unroll
-    for (int i = 0; i < P::N; ++i) out[i] = r.v[i];
+    fp_pack<P>(w, fp_reduce_full<P>(fp_mul<P>(a, o)));
 }
 
-// a^e, e as little-endian 32-bit limbs (public exponent; not constant time)
+// storage of Montgomery-form values (semi-reduced, < 2p < 2^(32 W)) in HBM / host buffers
 template <class P>
-ZK_HD Fp<P> fp_pow(const Fp<P>& a, const uint32_t* e, int nlimbs) {
+ZK_HD Fp<P> fp_load(const uint32_t* w) {
+    return fp_unpack<P>(w);
+}
+template <class P>
+ZK_HD void fp_store(uint32_t* w, const Fp<P>& a) {
+    fp_pack<P>(w, a);
+}
+
+// ---- helpers on canonical 32-bit words ------------------------------------------------------------------
+
+// r = a - p on W-word integers, returns the final borrow (1 when a < p)
+template <class P>
+ZK_HD uint32_t fp_sub_mod_raw(uint32_t* r, const uint32_t* a) {
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < P::W; ++i) {
+        uint64_t t = (uint64_t)a[i] - P::MOD[i] - borrow;
+        r[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+    return (uint32_t)borrow;
+}
+
+// lexicographic "a > (p-1)/2" on the canonical value (the sign flag of the compressed codecs)
+template <class P>
+ZK_HD bool fp_canonical_gt_half(const uint32_t* c) {
+    for (int i = P::W - 1; i >= 0; --i) {
+        if (c[i] != P::HALF[i]) return c[i] > P::HALF[i];
+    }
+    return false;
+}
+
+// a^e, e as little-endian 32-bit words (public exponent; not constant time)
+template <class P>
+ZK_HD Fp<P> fp_pow(const Fp<P>& a, const uint32_t* e, int nwords) {
     Fp<P> acc = fp_one<P>();
     bool started = false;
-    for (int i = nlimbs * 32 - 1; i >= 0; --i) {
+    for (int i = nwords * 32 - 1; i >= 0; --i) {
         if (started) acc = fp_sqr<P>(acc);
         if ((e[i >> 5] >> (i & 31)) & 1) {
             acc = started ? fp_mul<P>(acc, a) : a;
@@ -245,19 +346,10 @@ ZK_HD Fp<P> fp_pow(const Fp<P>& a, const uint32_t* e, int nlimbs) {
 
 template <class P>
 ZK_HD Fp<P> fp_inv(const Fp<P>& a) {
-    return fp_pow<P>(a, P::PM2, P::N);
+    return fp_pow<P>(a, P::PM2, P::W);
 }
 
-// lexicographic "a > (p-1)/2" on the canonical value (the sign flag of the compressed codecs)
-template <class P>
-ZK_HD bool fp_canonical_gt_half(const uint32_t* c) {
-    for (int i = P::N - 1; i >= 0; --i) {
-        if (c[i] != P::HALF[i]) return c[i] > P::HALF[i];
-    }
-    return false;
-}
-
-// ---- quadratic extension Fp[u]/(u^2 + 1) (both curves use this tower for G2) ------------
+// ---- quadratic extension Fp[u]/(u^2 + 1) (both curves use this tower for G2) ----------------------------
 
 template <class P>
 struct Fp2 {
@@ -278,6 +370,7 @@ template <class P>
 ZK_HD Fp2<P> fp2_mul(const Fp2<P>& a, const Fp2<P>& b) {
     Fp<P> t0 = fp_mul<P>(a.c0, b.c0);
     Fp<P> t1 = fp_mul<P>(a.c1, b.c1);
+    // (a0 + a1), (b0 + b1) < 4p each: 16 <= R/p, so the product stays below 2p
     Fp<P> t2 = fp_mul<P>(fp_add<P>(a.c0, a.c1), fp_add<P>(b.c0, b.c1));
     return {fp_sub<P>(t0, t1), fp_sub<P>(fp_sub<P>(t2, t0), t1)};
 }
@@ -295,13 +388,15 @@ ZK_HD Fp2<P> fp2_inv(const Fp2<P>& a) {
     return {fp_mul<P>(a.c0, d), fp_neg<P>(fp_mul<P>(a.c1, d))};
 }
 
-// ---- uniform "field ops" facades so curve code is generic over Fp / Fp2 -------------------
+// ---- uniform "field ops" facades so curve code is generic over Fp / Fp2 ---------------------------------
+// LIMBS = 32-bit words per element in memory; REGS = 32-bit registers per element.
 
 template <class P>
 struct FpOps {
     typedef Fp<P> T;
     typedef P Params;
-    static constexpr int LIMBS = P::N;  // 32-bit words per element
+    static constexpr int LIMBS = P::W;
+    static constexpr int REGS = P::N;
     static ZK_HD T zero() { return fp_zero<P>(); }
     static ZK_HD T one() { return fp_one<P>(); }
     static ZK_HD T add(const T& a, const T& b) { return fp_add<P>(a, b); }
@@ -315,13 +410,16 @@ struct FpOps {
     static ZK_HD bool eq(const T& a, const T& b) { return fp_eq<P>(a, b); }
     static ZK_HD T from_canonical(const uint32_t* w) { return fp_from_canonical<P>(w); }
     static ZK_HD void to_canonical(uint32_t* w, const T& a) { fp_to_canonical<P>(w, a); }
+    static ZK_HD T load(const uint32_t* w) { return fp_load<P>(w); }
+    static ZK_HD void store(uint32_t* w, const T& a) { fp_store<P>(w, a); }
 };
 
 template <class P>
 struct Fp2Ops {
     typedef Fp2<P> T;
     typedef P Params;
-    static constexpr int LIMBS = 2 * P::N;
+    static constexpr int LIMBS = 2 * P::W;
+    static constexpr int REGS = 2 * P::N;
     static ZK_HD T zero() { return fp2_zero<P>(); }
     static ZK_HD T one() { return fp2_one<P>(); }
     static ZK_HD T add(const T& a, const T& b) { return fp2_add<P>(a, b); }
@@ -334,11 +432,16 @@ struct Fp2Ops {
     static ZK_HD bool is_zero(const T& a) { return fp2_is_zero<P>(a); }
     static ZK_HD bool eq(const T& a, const T& b) { return fp2_eq<P>(a, b); }
     static ZK_HD T from_canonical(const uint32_t* w) {
-        return {fp_from_canonical<P>(w), fp_from_canonical<P>(w + P::N)};
+        return {fp_from_canonical<P>(w), fp_from_canonical<P>(w + P::W)};
     }
     static ZK_HD void to_canonical(uint32_t* w, const T& a) {
         fp_to_canonical<P>(w, a.c0);
-        fp_to_canonical<P>(w + P::N, a.c1);
+        fp_to_canonical<P>(w + P::W, a.c1);
+    }
+    static ZK_HD T load(const uint32_t* w) { return {fp_load<P>(w), fp_load<P>(w + P::W)}; }
+    static ZK_HD void store(uint32_t* w, const T& a) {
+        fp_store<P>(w, a.c0);
+        fp_store<P>(w + P::W, a.c1);
     }
 };
 

@@ -49,9 +49,9 @@ static bool point_on_curve(const Affine<typename G::F>& p) {
 
 template <class FrP>
 static void reduce_scalar(uint32_t* k, const uint64_t* scalar) {
-    memcpy(k, scalar, FrP::N * 4);
+    memcpy(k, scalar, FrP::W * 4);
     for (int r = 0; r < 10; ++r) {
-        uint32_t t[FrP::N];
+        uint32_t t[FrP::W];
         if (fp_sub_mod_raw<FrP>(t, k)) break;
         memcpy(k, t, sizeof(t));
     }
@@ -61,7 +61,7 @@ static void reduce_scalar(uint32_t* k, const uint64_t* scalar) {
 
 template <class P>
 static bool fp_sqrt(const Fp<P>& a, Fp<P>* out) {
-    Fp<P> s = fp_pow<P>(a, P::SQRT_E, P::N);
+    Fp<P> s = fp_pow<P>(a, P::SQRT_E, P::W);
     if (!fp_eq<P>(fp_sqr<P>(s), a)) return false;
     *out = s;
     return true;
@@ -100,7 +100,7 @@ template <class P> static bool coord_sqrt(const Fp2<P>& a, Fp2<P>* o) { return f
 // "y is the lexicographically larger of {y, -y}" (ark: y > -y; Fp2 compares c1 first, then c0)
 template <class P>
 static bool coord_is_larger(const Fp<P>& y) {
-    uint32_t c[P::N];
+    uint32_t c[P::W];
     fp_to_canonical<P>(c, y);
     return fp_canonical_gt_half<P>(c);
 }
@@ -127,7 +127,7 @@ static void bytes_to_words(uint32_t* w, int nwords, const uint8_t* src, int nbyt
 }
 template <class P>
 static bool canonical_lt_mod(const uint32_t* c) {
-    uint32_t t[P::N];
+    uint32_t t[P::W];
     return fp_sub_mod_raw<P>(t, c) != 0;
 }
 
@@ -137,7 +137,7 @@ static int compress_impl(const uint64_t* a, uint8_t* out) {
     typedef typename F::Params P;
     constexpr bool bls = G::CURVE == ZK_CURVE_BLS12_381;
     constexpr int fb = bls ? 48 : 32;            // bytes per base-field element
-    constexpr int comps = F::LIMBS / P::N;       // 1 (G1) or 2 (G2)
+    constexpr int comps = F::LIMBS / P::W;       // 1 (G1) or 2 (G2)
     constexpr int total = fb * comps;
     Affine<F> p = load_point<G>(a);
     memset(out, 0, total);
@@ -150,12 +150,12 @@ static int compress_impl(const uint64_t* a, uint8_t* out) {
     bool larger = coord_is_larger(p.y);
     if (bls) {
         // zcash: big-endian, c1 first for Fp2; bit7 compressed, bit6 infinity, bit5 y-largest
-        for (int k = 0; k < comps; ++k) words_to_bytes(out + k * fb, xw + (comps - 1 - k) * P::N, fb, true);
+        for (int k = 0; k < comps; ++k) words_to_bytes(out + k * fb, xw + (comps - 1 - k) * P::W, fb, true);
         out[0] |= 0x80;
         if (larger) out[0] |= 0x20;
     } else {
         // ark-serialize: little-endian, c0 first; flags in the top bits of the last byte
-        for (int k = 0; k < comps; ++k) words_to_bytes(out + k * fb, xw + k * P::N, fb, false);
+        for (int k = 0; k < comps; ++k) words_to_bytes(out + k * fb, xw + k * P::W, fb, false);
         if (larger) out[total - 1] |= 0x80;
     }
     return ZK_OK;
@@ -168,7 +168,7 @@ static int decompress_impl(const uint8_t* in, uint64_t* out) {
     typedef typename G::Fr FrP;
     constexpr bool bls = G::CURVE == ZK_CURVE_BLS12_381;
     constexpr int fb = bls ? 48 : 32;
-    constexpr int comps = F::LIMBS / P::N;
+    constexpr int comps = F::LIMBS / P::W;
     constexpr int total = fb * comps;
     uint8_t buf[total];
     memcpy(buf, in, total);
@@ -188,8 +188,8 @@ static int decompress_impl(const uint8_t* in, uint64_t* out) {
     }
     uint32_t xw[F::LIMBS];
     for (int k = 0; k < comps; ++k) {
-        if (bls) bytes_to_words(xw + (comps - 1 - k) * P::N, P::N, buf + k * fb, fb, true);
-        else bytes_to_words(xw + k * P::N, P::N, buf + k * fb, fb, false);
+        if (bls) bytes_to_words(xw + (comps - 1 - k) * P::W, P::W, buf + k * fb, fb, true);
+        else bytes_to_words(xw + k * P::W, P::W, buf + k * fb, fb, false);
     }
     if (inf) {
         for (int i = 0; i < F::LIMBS; ++i)
@@ -199,7 +199,7 @@ static int decompress_impl(const uint8_t* in, uint64_t* out) {
         return ZK_OK;
     }
     for (int k = 0; k < comps; ++k)
-        if (!canonical_lt_mod<P>(xw + k * P::N)) return fail(ZK_ERR_POINT, "Cannot deserialize point: x is not a field element");
+        if (!canonical_lt_mod<P>(xw + k * P::W)) return fail(ZK_ERR_POINT, "Cannot deserialize point: x is not a field element");
     typename F::T x = F::from_canonical(xw);
     typename F::T rhs = F::add(F::mul(F::sqr(x), x), F::from_canonical(CurveConsts<G>::b()));
     typename F::T y;
@@ -207,9 +207,9 @@ static int decompress_impl(const uint8_t* in, uint64_t* out) {
     if (coord_is_larger(y) != larger) y = F::neg(y);
     Affine<F> p = {x, y};
     // subgroup check (ark's deserialize_compressed validates): r * P == infinity
-    uint32_t r[FrP::N];
+    uint32_t r[FrP::W];
     memcpy(r, FrP::MOD, sizeof(r));
-    if (!xyzz_is_inf<F>(xyzz_scalar_mul<F>(p, r, FrP::N))) return fail(ZK_ERR_POINT, "Cannot deserialize point: not in the prime-order subgroup");
+    if (!xyzz_is_inf<F>(xyzz_scalar_mul<F>(p, r, FrP::W))) return fail(ZK_ERR_POINT, "Cannot deserialize point: not in the prime-order subgroup");
     store_point<G>(out, p);
     return ZK_OK;
 }
@@ -239,14 +239,14 @@ static int lagrange_impl(uint64_t n_in, const uint64_t* tau_c, uint64_t* out) {
         Fp<P> cur = fp_one<P>();
         for (uint64_t i = 0; i < n; ++i) {
             Fp<P> v = fp_eq<P>(cur, tau) ? fp_one<P>() : fp_zero<P>();
-            fp_to_canonical<P>(o + i * P::N, v);
+            fp_to_canonical<P>(o + i * P::W, v);
             cur = fp_mul<P>(cur, w);
         }
         return ZK_OK;
     }
-    uint32_t nn[P::N] = {0};
+    uint32_t nn[P::W] = {0};
     nn[0] = (uint32_t)n;
-    if (P::N > 1) nn[1] = (uint32_t)(n >> 32);
+    nn[1] = (uint32_t)(n >> 32);
     Fp<P> zn = fp_mul<P>(z, fp_inv<P>(fp_from_canonical<P>(nn)));
     // L_i = zn * w^i / (tau - w^i): batch-invert the denominators
     std::vector<Fp<P>> den(n), pre(n), wi(n);
@@ -263,7 +263,7 @@ static int lagrange_impl(uint64_t n_in, const uint64_t* tau_c, uint64_t* out) {
         Fp<P> di = fp_mul<P>(inv, pre[i]);
         inv = fp_mul<P>(inv, den[i]);
         Fp<P> l = fp_mul<P>(fp_mul<P>(zn, wi[i]), di);
-        fp_to_canonical<P>(o + i * P::N, l);
+        fp_to_canonical<P>(o + i * P::W, l);
     }
     return ZK_OK;
 }
@@ -366,9 +366,9 @@ int zk_point_mul(int curve, int group, const uint64_t* a, const uint64_t* scalar
 #define CALL(G)                                                              \
     {                                                                        \
         typedef G::F F;                                                      \
-        uint32_t k[G::Fr::N];                                                \
+        uint32_t k[G::Fr::W];                                                \
         reduce_scalar<G::Fr>(k, scalar);                                     \
-        XYZZ<F> r = xyzz_scalar_mul<F>(load_point<G>(a), k, G::Fr::N);       \
+        XYZZ<F> r = xyzz_scalar_mul<F>(load_point<G>(a), k, G::Fr::W);       \
         store_point<G>(out, xyzz_to_affine<F>(r));                           \
         return ZK_OK;                                                        \
     }

@@ -49,27 +49,43 @@ __device__ __forceinline__ void store_words(uint32_t* dst, const uint32_t* src) 
     for (int i = 0; i < WORDS / 4; ++i) q[i] = make_uint4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
 }
 
-// Fp / Fp2 elements are plain arrays of u32, so points can be moved as word arrays
+// Points in memory are packed 32-bit words (LIMBS per coordinate); registers hold 29-bit limbs.
 template <class F>
 __device__ __forceinline__ Affine<F> load_affine(const uint32_t* p) {
-    Affine<F> a;
-    load_words<2 * F::LIMBS>(reinterpret_cast<uint32_t*>(&a), p);
-    return a;
+    uint32_t w[2 * F::LIMBS];
+    load_words<2 * F::LIMBS>(w, p);
+    return {F::load(w), F::load(w + F::LIMBS)};
 }
 template <class F>
 __device__ __forceinline__ void store_affine(uint32_t* p, const Affine<F>& a) {
-    store_words<2 * F::LIMBS>(p, reinterpret_cast<const uint32_t*>(&a));
+    uint32_t w[2 * F::LIMBS];
+    F::store(w, a.x);
+    F::store(w + F::LIMBS, a.y);
+    store_words<2 * F::LIMBS>(p, w);
 }
 template <class F>
 __device__ __forceinline__ XYZZ<F> load_xyzz(const uint32_t* p) {
-    XYZZ<F> a;
-    load_words<4 * F::LIMBS>(reinterpret_cast<uint32_t*>(&a), p);
-    return a;
+    uint32_t w[4 * F::LIMBS];
+    load_words<4 * F::LIMBS>(w, p);
+    return {F::load(w), F::load(w + F::LIMBS), F::load(w + 2 * F::LIMBS), F::load(w + 3 * F::LIMBS)};
 }
 template <class F>
 __device__ __forceinline__ void store_xyzz(uint32_t* p, const XYZZ<F>& a) {
-    store_words<4 * F::LIMBS>(p, reinterpret_cast<const uint32_t*>(&a));
+    uint32_t w[4 * F::LIMBS];
+    F::store(w, a.X);
+    F::store(w + F::LIMBS, a.Y);
+    F::store(w + 2 * F::LIMBS, a.ZZ);
+    F::store(w + 3 * F::LIMBS, a.ZZZ);
+    store_words<4 * F::LIMBS>(p, w);
 }
+template <class F>
+static XYZZ<F> load_xyzz_host(const uint32_t* w) {
+    return {F::load(w), F::load(w + F::LIMBS), F::load(w + 2 * F::LIMBS), F::load(w + 3 * F::LIMBS)};
+}
+
+// register-form copies (LDS staging, wave shuffles): XYZZ<F> is a plain struct of u32 registers
+template <class F>
+struct XyzzRegs { static constexpr int COUNT = sizeof(XYZZ<F>) / 4; };
 
 template <class F>
 __device__ __forceinline__ XYZZ<F> shfl_xor_xyzz(const XYZZ<F>& a, int mask) {
@@ -77,7 +93,21 @@ __device__ __forceinline__ XYZZ<F> shfl_xor_xyzz(const XYZZ<F>& a, int mask) {
     const uint32_t* s = reinterpret_cast<const uint32_t*>(&a);
     uint32_t* d = reinterpret_cast<uint32_t*>(&r);
 #pragma unroll
-    for (int i = 0; i < 4 * F::LIMBS; ++i) d[i] = __shfl_xor(s[i], mask, 64);
+    for (int i = 0; i < XyzzRegs<F>::COUNT; ++i) d[i] = __shfl_xor(s[i], mask, 64);
+    return r;
+}
+template <class F>
+__device__ __forceinline__ void lds_put_xyzz(uint32_t* slot, const XYZZ<F>& a) {
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(&a);
+#pragma unroll
+    for (int i = 0; i < XyzzRegs<F>::COUNT; ++i) slot[i] = s[i];
+}
+template <class F>
+__device__ __forceinline__ XYZZ<F> lds_get_xyzz(const uint32_t* slot) {
+    XYZZ<F> r;
+    uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (int i = 0; i < XyzzRegs<F>::COUNT; ++i) d[i] = slot[i];
     return r;
 }
 
@@ -90,7 +120,7 @@ struct DigitBias {
 template <class FrP>
 __global__ void digits_kernel(const uint32_t* __restrict__ scalars, uint32_t n, int c, int nwin, DigitBias bias,
                               uint16_t* __restrict__ dig) {
-    constexpr int N = FrP::N;
+    constexpr int N = FrP::W;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t s[N + 1];
@@ -356,17 +386,18 @@ __global__ __launch_bounds__(HS_THREADS) void weighted_sum_kernel(const uint32_t
                                                                   uint32_t* __restrict__ out) {
     typedef typename G::F F;
     constexpr int XW = 4 * F::LIMBS;
-    __shared__ uint32_t sh[HS_THREADS * XW];
+    constexpr int RW = XyzzRegs<F>::COUNT;
+    __shared__ uint32_t sh[HS_THREADS * RW];
     const uint32_t j = threadIdx.x;
     const bool first = blockIdx.x < n0;
     const uint32_t m = first ? m0 : m1;
     const uint32_t* arr = first ? in0 + (size_t)blockIdx.x * m0 * XW : in1 + (size_t)(blockIdx.x - n0) * m1 * XW;
     XYZZ<F> v = j < m ? load_xyzz<F>(arr + (size_t)j * XW) : xyzz_inf<F>();
     for (uint32_t off = 1; off < m; off <<= 1) {
-        store_xyzz<F>(sh + (size_t)j * XW, v);
+        lds_put_xyzz<F>(sh + (size_t)j * RW, v);
         __syncthreads();
         if (j + off < m) {
-            XYZZ<F> o = load_xyzz<F>(sh + (size_t)(j + off) * XW);
+            XYZZ<F> o = lds_get_xyzz<F>(sh + (size_t)(j + off) * RW);
             v = xyzz_add<F>(v, o);
         }
         __syncthreads();
@@ -377,10 +408,10 @@ __global__ __launch_bounds__(HS_THREADS) void weighted_sum_kernel(const uint32_t
     uint32_t top = 1;
     while (top < m) top <<= 1;
     for (uint32_t off = top / 2; off >= 1; off >>= 1) {
-        store_xyzz<F>(sh + (size_t)j * XW, v);
+        lds_put_xyzz<F>(sh + (size_t)j * RW, v);
         __syncthreads();
         if (j < off) {
-            XYZZ<F> o = load_xyzz<F>(sh + (size_t)(j + off) * XW);
+            XYZZ<F> o = lds_get_xyzz<F>(sh + (size_t)(j + off) * RW);
             v = xyzz_add<F>(v, o);
         }
         __syncthreads();
@@ -414,20 +445,20 @@ __global__ __launch_bounds__(128) void batch_mul_kernel(const uint32_t* __restri
     constexpr int AW = 2 * F::LIMBS;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t k[FrP::N];
-    load_words<FrP::N>(k, scalars + i * FrP::N);
+    uint32_t k[FrP::W];
+    load_words<FrP::W>(k, scalars + i * FrP::W);
     for (int r = 0; r < 10; ++r) {
-        uint32_t t[FrP::N];
+        uint32_t t[FrP::W];
         if (fp_sub_mod_raw<FrP>(t, k)) break;
 #pragma unroll
-        for (int l = 0; l < FrP::N; ++l) k[l] = t[l];
+        for (int l = 0; l < FrP::W; ++l) k[l] = t[l];
     }
     uint32_t w[AW];
     load_words<AW>(w, bases + (broadcast ? 0 : i * AW));
     Affine<F> p;
     p.x = F::from_canonical(w);
     p.y = F::from_canonical(w + F::LIMBS);
-    XYZZ<F> acc = xyzz_scalar_mul<F>(p, k, FrP::N);
+    XYZZ<F> acc = xyzz_scalar_mul<F>(p, k, FrP::W);
     Affine<F> a = xyzz_to_affine<F>(acc);
     F::to_canonical(w, a.x);
     F::to_canonical(w + F::LIMBS, a.y);
@@ -533,7 +564,7 @@ struct MsmPlan : MsmPlanBase {
             ZK_HIP(e);
         }
         ZK_HIP(hipGetLastError());
-        ZK_HIP(hipMalloc(&d_scalars, n * FrP::N * 4));
+        ZK_HIP(hipMalloc(&d_scalars, n * FrP::W * 4));
         ZK_HIP(hipMalloc(&d_dig, (size_t)nwin * n * 2));
         ZK_HIP(hipMalloc(&d_hist, (size_t)nwin * nchunk * B * 4));
         ZK_HIP(hipMalloc(&d_total, n_keys * 4));
@@ -578,7 +609,7 @@ struct MsmPlan : MsmPlanBase {
         if (m > 0) {
             const uint32_t* sc = (const uint32_t*)scalars;
             if (!on_device) {
-                ZK_HIP(hipMemcpyAsync(d_scalars, scalars, (size_t)m * FrP::N * 4, hipMemcpyHostToDevice, st));
+                ZK_HIP(hipMemcpyAsync(d_scalars, scalars, (size_t)m * FrP::W * 4, hipMemcpyHostToDevice, st));
                 sc = d_scalars;
             }
             const uint32_t n_keys = (uint32_t)w_count * B;
@@ -623,9 +654,9 @@ struct MsmPlan : MsmPlanBase {
             ZK_HIP(hipStreamSynchronize(st));
             // 8. host tail: window sum W = C * S_R + S_C + T ; Horner over windows
             for (int wl = w_count - 1; wl >= 0; --wl) {
-                const XYZZ<F>* rowp = reinterpret_cast<const XYZZ<F>*>(h_final + (size_t)wl * 2 * XW);
-                const XYZZ<F>* colp = reinterpret_cast<const XYZZ<F>*>(h_final + ((size_t)w_count * 2 + (size_t)wl * 2) * XW);
-                XYZZ<F> sr = rowp[0], tot = rowp[1], scol = colp[0];
+                const uint32_t* rowp = h_final + (size_t)wl * 2 * XW;
+                const uint32_t* colp = h_final + ((size_t)w_count * 2 + (size_t)wl * 2) * XW;
+                XYZZ<F> sr = load_xyzz_host<F>(rowp), tot = load_xyzz_host<F>(rowp + XW), scol = load_xyzz_host<F>(colp);
                 for (uint32_t k = 1; k < C; k <<= 1) sr = xyzz_dbl<F>(sr);
                 XYZZ<F> wsum = xyzz_add<F>(xyzz_add<F>(sr, scol), tot);
                 if (wl != w_count - 1) for (int k = 0; k < c; ++k) total = xyzz_dbl<F>(total);
@@ -669,10 +700,10 @@ static int batch_mul_impl(uint64_t n, const uint64_t* scalars, const uint64_t* b
     uint32_t *ds = nullptr, *db = nullptr, *dout = nullptr;
     int rc = ZK_OK;
     uint64_t nb = broadcast ? 1 : n;
-    ZK_HIP(hipMalloc(&ds, n * FrP::N * 4));
+    ZK_HIP(hipMalloc(&ds, n * FrP::W * 4));
     do {
         if (hipMalloc(&db, nb * AW * 4) != hipSuccess || hipMalloc(&dout, n * AW * 4) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMalloc failed"); break; }
-        if (hipMemcpy(ds, scalars, n * FrP::N * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        if (hipMemcpy(ds, scalars, n * FrP::W * 4, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(db, bases, nb * AW * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy H2D failed"); break; }
         hipLaunchKernelGGL(batch_mul_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, ds, db, broadcast, n, dout);
         if (hipGetLastError() != hipSuccess || hipMemcpy(out, dout, n * AW * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "batch_mul kernel / D2H failed"); break; }

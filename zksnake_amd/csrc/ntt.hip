@@ -24,23 +24,26 @@ constexpr int NTT_TILE_LOG = 10;  // 1024 elements = 32 KiB of LDS per workgroup
 constexpr int NTT_THREADS = 256;
 constexpr int NTT_Q = 3;          // 2^3 contiguous elements (256 B) per row of a strided tile
 
+// an element in memory is W packed 32-bit words; in registers N 29-bit limbs
 template <class P>
 __device__ __forceinline__ Fp<P> load_fr(const uint32_t* p) {
-    Fp<P> r;
+    uint32_t w[P::W];
     const uint4* q = reinterpret_cast<const uint4*>(p);
 #pragma unroll
-    for (int i = 0; i < P::N / 4; ++i) {
+    for (int i = 0; i < P::W / 4; ++i) {
         uint4 t = q[i];
-        r.v[4 * i] = t.x; r.v[4 * i + 1] = t.y; r.v[4 * i + 2] = t.z; r.v[4 * i + 3] = t.w;
+        w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
     }
-    return r;
+    return fp_unpack<P>(w);
 }
 
 template <class P>
 __device__ __forceinline__ void store_fr(uint32_t* p, const Fp<P>& a) {
+    uint32_t w[P::W];
+    fp_pack<P>(w, a);
     uint4* q = reinterpret_cast<uint4*>(p);
 #pragma unroll
-    for (int i = 0; i < P::N / 4; ++i) q[i] = make_uint4(a.v[4 * i], a.v[4 * i + 1], a.v[4 * i + 2], a.v[4 * i + 3]);
+    for (int i = 0; i < P::W / 4; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 
 // ---- twiddle generation -------------------------------------------------------------------
@@ -51,7 +54,7 @@ __global__ void twiddle_kernel(uint32_t* out, Fp<P> w, uint32_t count) {
     if (k >= count) return;
     uint32_t e[1] = {k};
     Fp<P> r = fp_pow<P>(w, e, 1);
-    store_fr<P>(out + (size_t)k * P::N, r);
+    store_fr<P>(out + (size_t)k * P::W, r);
 }
 
 // ---- butterfly passes -----------------------------------------------------------------------
@@ -63,7 +66,8 @@ template <class P>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(uint32_t* __restrict__ data,
                                                                const uint32_t* __restrict__ tw, int log_n,
                                                                int s_hi, int m, int q) {
-    constexpr int N = P::N;
+    constexpr int N = P::N;  // register limbs (LDS is limb-major)
+    constexpr int W = P::W;  // words per element in HBM
     __shared__ uint32_t lds[N][1 << NTT_TILE_LOG];
     const int tile_log = m + q;
     const int tile = 1 << tile_log;
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(uint32_t* __restr
     for (int e = threadIdx.x; e < tile; e += NTT_THREADS) {
         uint32_t mid = e >> q, lo_in = e & ((1u << q) - 1);
         uint32_t idx = base | (mid << s_lo) | lo_in;
-        Fp<P> x = load_fr<P>(data + (size_t)idx * N);
+        Fp<P> x = load_fr<P>(data + (size_t)idx * W);
 #pragma unroll
         for (int l = 0; l < N; ++l) lds[l][e] = x.v[l];
     }
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(uint32_t* __restr
             Fp<P> x, y;
 #pragma unroll
             for (int l = 0; l < N; ++l) { x.v[l] = lds[l][e0]; y.v[l] = lds[l][e1]; }
-            Fp<P> w = load_fr<P>(tw + (size_t)k * N);
+            Fp<P> w = load_fr<P>(tw + (size_t)k * W);
             Fp<P> sum = fp_add<P>(x, y);
             Fp<P> dif = fp_mul<P>(fp_sub<P>(x, y), w);
 #pragma unroll
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(uint32_t* __restr
         Fp<P> x;
 #pragma unroll
         for (int l = 0; l < N; ++l) x.v[l] = lds[l][e];
-        store_fr<P>(data + (size_t)idx * N, x);
+        store_fr<P>(data + (size_t)idx * W, x);
     }
 }
 
@@ -121,15 +125,19 @@ __global__ void bitrev_scale_kernel(uint32_t* data, int log_n, Fp<P> scale, int 
     if (i >= (1u << log_n)) return;
     uint32_t j = log_n == 0 ? 0 : (__brev(i) >> (32 - log_n));
     if (i > j) return;
-    Fp<P> a = load_fr<P>(data + (size_t)i * P::N);
+    // the butterfly passes leave semi-reduced values (< 2p): this last pass stores canonical ones
+    Fp<P> a = load_fr<P>(data + (size_t)i * P::W);
+    if (use_scale) a = fp_mul<P>(a, scale);
+    a = fp_reduce_full<P>(a);
     if (i == j) {
-        if (use_scale) store_fr<P>(data + (size_t)i * P::N, fp_mul<P>(a, scale));
+        store_fr<P>(data + (size_t)i * P::W, a);
         return;
     }
-    Fp<P> b = load_fr<P>(data + (size_t)j * P::N);
-    if (use_scale) { a = fp_mul<P>(a, scale); b = fp_mul<P>(b, scale); }
-    store_fr<P>(data + (size_t)i * P::N, b);
-    store_fr<P>(data + (size_t)j * P::N, a);
+    Fp<P> b = load_fr<P>(data + (size_t)j * P::W);
+    if (use_scale) b = fp_mul<P>(b, scale);
+    b = fp_reduce_full<P>(b);
+    store_fr<P>(data + (size_t)i * P::W, b);
+    store_fr<P>(data + (size_t)j * P::W, a);
 }
 
 // x[i] *= g^(+-i) with g = w (table holds w^k for k < n/2; w^(n/2) = -1)
@@ -139,10 +147,10 @@ __global__ void coset_scale_kernel(uint32_t* data, const uint32_t* tw, uint32_t 
     if (i >= n) return;
     if (n == 1) return;
     uint32_t half = n >> 1;
-    Fp<P> w = load_fr<P>(tw + (size_t)(i & (half - 1)) * P::N);
+    Fp<P> w = load_fr<P>(tw + (size_t)(i & (half - 1)) * P::W);
     if (i >= half) w = fp_neg<P>(w);
-    Fp<P> a = load_fr<P>(data + (size_t)i * P::N);
-    store_fr<P>(data + (size_t)i * P::N, fp_mul<P>(a, w));
+    Fp<P> a = load_fr<P>(data + (size_t)i * P::W);
+    store_fr<P>(data + (size_t)i * P::W, fp_reduce_full<P>(fp_mul<P>(a, w)));
 }
 
 // op: 0 mul, 1 add, 2 sub on canonical data.  mul: mont(mont(a,b), R^2) = a*b
@@ -150,11 +158,11 @@ template <class P>
 __global__ void vec_op_kernel(int op, uint64_t n, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fp<P> x = load_fr<P>(a + i * P::N), y = load_fr<P>(b + i * P::N), z;
+    Fp<P> x = load_fr<P>(a + i * P::W), y = load_fr<P>(b + i * P::W), z;
     if (op == 0) z = fp_mul<P>(fp_mul<P>(x, y), fp_const<P>(P::R2));
     else if (op == 1) z = fp_add<P>(x, y);
     else z = fp_sub<P>(x, y);
-    store_fr<P>(out + i * P::N, z);
+    store_fr<P>(out + i * P::W, fp_reduce_full<P>(z));
 }
 
 // reduce every element below the modulus (inputs of the host API may be >= r)
@@ -162,14 +170,21 @@ template <class P>
 __global__ void canon_kernel(uint64_t n, uint32_t* a) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fp<P> x = load_fr<P>(a + i * P::N);
-    for (int k = 0; k < 10; ++k) {
-        uint32_t t[P::N];
-        if (fp_sub_mod_raw<P>(t, x.v)) break;
+    uint32_t x[P::W];
+    uint4* q = reinterpret_cast<uint4*>(a + i * P::W);
 #pragma unroll
-        for (int l = 0; l < P::N; ++l) x.v[l] = t[l];
+    for (int k = 0; k < P::W / 4; ++k) {
+        uint4 t = q[k];
+        x[4 * k] = t.x; x[4 * k + 1] = t.y; x[4 * k + 2] = t.z; x[4 * k + 3] = t.w;
     }
-    store_fr<P>(a + i * P::N, x);
+    for (int k = 0; k < 10; ++k) {
+        uint32_t t[P::W];
+        if (fp_sub_mod_raw<P>(t, x)) break;
+#pragma unroll
+        for (int l = 0; l < P::W; ++l) x[l] = t[l];
+    }
+#pragma unroll
+    for (int k = 0; k < P::W / 4; ++k) q[k] = make_uint4(x[4 * k], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3]);
 }
 
 // q[j] = sum_{k>=1} c[j + k n],  rem[i] = c[i] + q[i]   (c has len coefficients)
@@ -184,12 +199,12 @@ __global__ void div_vanishing_kernel(uint64_t n, uint64_t len, const uint32_t* c
     // q[i] for i < qlen (may exceed n when len > 2n: then q[i] also folds further blocks)
     Fp<P> acc = fp_zero<P>();
     if (i < qlen) {
-        for (uint64_t j = i + n; j < len; j += n) acc = fp_add<P>(acc, load_fr<P>(c + j * P::N));
-        store_fr<P>(q + i * P::N, acc);
+        for (uint64_t j = i + n; j < len; j += n) acc = fp_add<P>(acc, load_fr<P>(c + j * P::W));
+        store_fr<P>(q + i * P::W, fp_reduce_full<P>(acc));
     }
     if (i < top) {
-        Fp<P> r = fp_add<P>(load_fr<P>(c + i * P::N), acc);
-        store_fr<P>(rem + i * P::N, r);
+        Fp<P> r = fp_reduce_full<P>(fp_add<P>(load_fr<P>(c + i * P::W), acc));
+        store_fr<P>(rem + i * P::W, r);
         if (!fp_is_zero<P>(r)) atomicOr(nonzero, 1);
     }
 }
@@ -204,11 +219,11 @@ __global__ void spmv_kernel(uint64_t n_rows, const uint32_t* __restrict__ row_pt
     if (row >= n_rows) return;
     Fp<P> acc = fp_zero<P>();
     for (uint32_t k = row_ptr[row]; k < row_ptr[row + 1]; ++k) {
-        Fp<P> v = load_fr<P>(vals + (size_t)k * P::N);
-        Fp<P> x = load_fr<P>(w + (size_t)cols[k] * P::N);
+        Fp<P> v = load_fr<P>(vals + (size_t)k * P::W);
+        Fp<P> x = load_fr<P>(w + (size_t)cols[k] * P::W);
         acc = fp_add<P>(acc, fp_mul<P>(v, x));  // v*x/R
     }
-    store_fr<P>(out + row * P::N, fp_mul<P>(acc, fp_const<P>(P::R2)));
+    store_fr<P>(out + row * P::W, fp_reduce_full<P>(fp_mul<P>(acc, fp_const<P>(P::R2))));
 }
 
 // QAP tail: flag |= (lo[i] + hi[i] - w[i] != 0)
@@ -216,7 +231,7 @@ template <class P>
 __global__ void qap_check_kernel(uint64_t n, const uint32_t* lo, const uint32_t* hi, const uint32_t* w, int* nonzero) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fp<P> r = fp_sub<P>(fp_add<P>(load_fr<P>(lo + i * P::N), load_fr<P>(hi + i * P::N)), load_fr<P>(w + i * P::N));
+    Fp<P> r = fp_sub<P>(fp_add<P>(load_fr<P>(lo + i * P::W), load_fr<P>(hi + i * P::W)), load_fr<P>(w + i * P::W));
     if (!fp_is_zero<P>(r)) atomicOr(nonzero, 1);
 }
 
@@ -245,7 +260,7 @@ static int get_twiddles(int curve, int log_n, TwiddleSet* out, hipStream_t strea
     if (it != g_twiddles.end()) { *out = it->second; return ZK_OK; }
     TwiddleSet ts;
     uint32_t count = log_n == 0 ? 1 : (1u << (log_n - 1));
-    size_t bytes = (size_t)count * P::N * 4;
+    size_t bytes = (size_t)count * P::W * 4;
     ZK_HIP(hipMalloc(&ts.fwd, bytes));
     ZK_HIP(hipMalloc(&ts.inv, bytes));
     hipLaunchKernelGGL(twiddle_kernel<P>, dim3((count + 255) / 256), dim3(256), 0, stream, ts.fwd, host_root<P>(log_n, false), count);
@@ -293,7 +308,7 @@ static int ntt_dev_impl(int curve, int inverse, int log_n, uint32_t* d, hipStrea
     }
     Fp<P> scale = fp_one<P>();
     if (inverse) {
-        uint32_t nn[P::N] = {0};
+        uint32_t nn[P::W] = {0};
         nn[0] = 1u << log_n;
         scale = fp_inv<P>(fp_from_canonical<P>(nn));
     }
@@ -328,7 +343,7 @@ static int ntt_host_impl(int curve, int inverse, int coset, uint64_t n_in, const
     uint64_t n = next_pow2_u64(size == 0 ? 1 : size);
     int log_n = log2_u64(n);
     if (log_n > P::TWO_ADICITY || log_n > 30) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
-    const size_t eb = P::N * 4;
+    const size_t eb = P::W * 4;
     uint32_t* d = nullptr;
     uint64_t alloc = n_in > n ? n_in : n;
     ZK_HIP(hipMalloc(&d, alloc * eb));
@@ -341,7 +356,7 @@ static int ntt_host_impl(int curve, int inverse, int coset, uint64_t n_in, const
             // fold modulo X^n - 1: x[i] += x[i + k n]
             for (uint64_t off = n; off < n_in; off += n) {
                 uint64_t cnt = n_in - off < n ? n_in - off : n;
-                rc = vec_op_dev_impl<P>(1, cnt, d, d + off * P::N, d, 0);
+                rc = vec_op_dev_impl<P>(1, cnt, d, d + off * P::W, d, 0);
                 if (rc) break;
             }
             if (rc) break;
@@ -359,7 +374,7 @@ static int ntt_host_impl(int curve, int inverse, int coset, uint64_t n_in, const
 template <class P>
 static int vec_op_host_impl(int op, uint64_t size, uint64_t n_a, const uint64_t* a, uint64_t n_b, const uint64_t* b, uint64_t* out) {
     if (size == 0) return ZK_OK;
-    const size_t eb = P::N * 4;
+    const size_t eb = P::W * 4;
     uint32_t* d = nullptr;
     ZK_HIP(hipMalloc(&d, 2 * size * eb));
     int rc = ZK_OK;
@@ -367,9 +382,9 @@ static int vec_op_host_impl(int op, uint64_t size, uint64_t n_a, const uint64_t*
         if (hipMemset(d, 0, 2 * size * eb) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemset failed"); break; }
         uint64_t ca = n_a < size ? n_a : size, cb = n_b < size ? n_b : size;
         if (ca && hipMemcpy(d, a, ca * eb, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy H2D failed"); break; }
-        if (cb && hipMemcpy(d + size * P::N, b, cb * eb, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy H2D failed"); break; }
+        if (cb && hipMemcpy(d + size * P::W, b, cb * eb, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy H2D failed"); break; }
         hipLaunchKernelGGL(canon_kernel<P>, dim3((unsigned)((2 * size + 255) / 256)), dim3(256), 0, 0, 2 * size, d);
-        rc = vec_op_dev_impl<P>(op, size, d, d + size * P::N, d, 0);
+        rc = vec_op_dev_impl<P>(op, size, d, d + size * P::W, d, 0);
         if (rc) break;
         if (hipMemcpy(out, d, size * eb, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy D2H failed"); break; }
     } while (0);
@@ -382,7 +397,7 @@ static int div_vanishing_host_impl(uint64_t n, uint64_t len, const uint64_t* coe
     if (n == 0) return fail(ZK_ERR_ARG, "vanishing polynomial of an empty domain");
     *rem_is_zero = 1;
     if (len == 0) return ZK_OK;
-    const size_t eb = P::N * 4;
+    const size_t eb = P::W * 4;
     uint64_t qlen = len > n ? len - n : 0, top = len < n ? len : n;
     uint32_t *dc = nullptr, *dq = nullptr, *dr = nullptr;
     int* dflag = nullptr;
@@ -411,9 +426,9 @@ static int qap_h_dev_impl(int curve, int log_n, uint32_t* a_u, uint32_t* b_v, co
                           uint32_t* work, int* divisible, hipStream_t stream) {
     if (log_n + 1 > P::TWO_ADICITY) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
     const uint64_t n = 1ull << log_n;
-    const size_t eb = P::N * 4;
+    const size_t eb = P::W * 4;
     uint32_t* U2 = work;
-    uint32_t* V2 = work + 2 * n * P::N;
+    uint32_t* V2 = work + 2 * n * P::W;
     int rc;
     if ((rc = ntt_dev_impl<P>(curve, 1, log_n, a_u, stream))) return rc;  // u
     if ((rc = ntt_dev_impl<P>(curve, 1, log_n, b_v, stream))) return rc;  // v
@@ -426,10 +441,10 @@ static int qap_h_dev_impl(int curve, int log_n, uint32_t* a_u, uint32_t* b_v, co
     if ((rc = ntt_dev_impl<P>(curve, 1, log_n + 1, U2, stream))) return rc;  // uv coefficients
     ZK_HIP(hipMemcpyAsync(V2, c, n * eb, hipMemcpyDeviceToDevice, stream));
     if ((rc = ntt_dev_impl<P>(curve, 1, log_n, V2, stream))) return rc;      // w
-    int* dflag = reinterpret_cast<int*>(V2 + n * P::N);  // second half of V2 is free now
+    int* dflag = reinterpret_cast<int*>(V2 + n * P::W);  // second half of V2 is free now
     ZK_HIP(hipMemsetAsync(dflag, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(qap_check_kernel<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, U2, U2 + n * P::N, V2, dflag);
-    ZK_HIP(hipMemcpyAsync(h, U2 + n * P::N, n * eb, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(qap_check_kernel<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, U2, U2 + n * P::W, V2, dflag);
+    ZK_HIP(hipMemcpyAsync(h, U2 + n * P::W, n * eb, hipMemcpyDeviceToDevice, stream));
     int flag = 0;
     ZK_HIP(hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, stream));
     ZK_HIP(hipStreamSynchronize(stream));
