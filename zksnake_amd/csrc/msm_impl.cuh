@@ -1,0 +1,693 @@
+// msm_impl.cuh -- Pippenger bucket multi-scalar multiplication over G1/G2 of BN254 and BLS12-381 on
+// gfx950, plus batched scalar multiplication.
+//
+// Stands in for multiscalar_mul_g1/_g2 (reference src/bn254/curve.rs:356-392,
+// src/bls12_381/curve.rs:366-402 -> ark-ec 0.4.2 VariableBaseMSM::msm) and
+// batch_multi_scalar_g1/_g2 (src/bn254/curve.rs:326-354).  The result of an MSM is a single
+// group element, returned as its unique affine representative, so any correct bucket method
+// is bit-identical with the reference's.
+//
+// Pipeline (one stream, no host round trip until the tail):
+//   1. digits      scalar -> signed c-bit window digits (bias trick: s + sum 2^(c-1) 2^(wc),
+//                  then plain bit fields), 2 B per (window, scalar), coalesced.
+//   2. histogram   one workgroup per (window, chunk): 2^(c-1) counters live in LDS (128 KiB at
+//                  c = 16), LDS atomics only; the table is flushed with coalesced stores.
+//   3. prefix/scan per-bucket prefix over chunks, bucket offsets, segment offsets.
+//   4. scatter     same grid as 2: LDS cursors, point references written bucket-sorted.
+//   5. accumulate  THE dominant kernel: one lane per bucket *segment* (<= S entries, so skewed
+//                  scalar distributions cannot starve a wave), XYZZ accumulator in registers,
+//                  bases gathered as whole 64..192-byte rows.
+//   6. combine     per-bucket sum of its segment partials.
+//   7. reduce      sum_b (b+1) B_b through the split b = hi*C + lo: wave-per-row / wave-per-column
+//                  sums (shuffle trees), then a log-depth suffix-scan on <=256 points per array.
+//   8. host tail   3 points per window come back; Horner over windows and the affine
+//                  conversion (one inversion) run on the host -- a lone GPU wave needs ~1.3 us per
+//                  field multiplication, the host ~50 ns.
+#pragma once
+#include <algorithm>
+#include <vector>
+#include "common.cuh"
+#include "msm_plan.h"
+
+namespace zkmi {
+
+
+// ---- device load/store of field elements / points (packed u32 words, 16-byte vectors) ------
+
+template <int WORDS>
+__device__ __forceinline__ void load_words(uint32_t* dst, const uint32_t* src) {
+    const uint4* q = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+    for (int i = 0; i < WORDS / 4; ++i) {
+        uint4 t = q[i];
+        dst[4 * i] = t.x; dst[4 * i + 1] = t.y; dst[4 * i + 2] = t.z; dst[4 * i + 3] = t.w;
+    }
+}
+template <int WORDS>
+__device__ __forceinline__ void store_words(uint32_t* dst, const uint32_t* src) {
+    uint4* q = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+    for (int i = 0; i < WORDS / 4; ++i) q[i] = make_uint4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+}
+
+// Points in memory are packed 32-bit words (LIMBS per coordinate); registers hold 29-bit limbs.
+template <class F>
+__device__ __forceinline__ Affine<F> load_affine(const uint32_t* p) {
+    uint32_t w[2 * F::LIMBS];
+    load_words<2 * F::LIMBS>(w, p);
+    return {F::load(w), F::load(w + F::LIMBS)};
+}
+template <class F>
+__device__ __forceinline__ void store_affine(uint32_t* p, const Affine<F>& a) {
+    uint32_t w[2 * F::LIMBS];
+    F::store(w, a.x);
+    F::store(w + F::LIMBS, a.y);
+    store_words<2 * F::LIMBS>(p, w);
+}
+template <class F>
+__device__ __forceinline__ XYZZ<F> load_xyzz(const uint32_t* p) {
+    uint32_t w[4 * F::LIMBS];
+    load_words<4 * F::LIMBS>(w, p);
+    return {F::load(w), F::load(w + F::LIMBS), F::load(w + 2 * F::LIMBS), F::load(w + 3 * F::LIMBS)};
+}
+template <class F>
+__device__ __forceinline__ void store_xyzz(uint32_t* p, const XYZZ<F>& a) {
+    uint32_t w[4 * F::LIMBS];
+    F::store(w, a.X);
+    F::store(w + F::LIMBS, a.Y);
+    F::store(w + 2 * F::LIMBS, a.ZZ);
+    F::store(w + 3 * F::LIMBS, a.ZZZ);
+    store_words<4 * F::LIMBS>(p, w);
+}
+template <class F>
+static XYZZ<F> load_xyzz_host(const uint32_t* w) {
+    return {F::load(w), F::load(w + F::LIMBS), F::load(w + 2 * F::LIMBS), F::load(w + 3 * F::LIMBS)};
+}
+
+// register-form copies (LDS staging, wave shuffles): XYZZ<F> is a plain struct of u32 registers
+template <class F>
+struct XyzzRegs { static constexpr int COUNT = sizeof(XYZZ<F>) / 4; };
+
+template <class F>
+__device__ __forceinline__ XYZZ<F> shfl_xor_xyzz(const XYZZ<F>& a, int mask) {
+    XYZZ<F> r;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(&a);
+    uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (int i = 0; i < XyzzRegs<F>::COUNT; ++i) d[i] = __shfl_xor(s[i], mask, 64);
+    return r;
+}
+template <class F>
+__device__ __forceinline__ void lds_put_xyzz(uint32_t* slot, const XYZZ<F>& a) {
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(&a);
+#pragma unroll
+    for (int i = 0; i < XyzzRegs<F>::COUNT; ++i) slot[i] = s[i];
+}
+template <class F>
+__device__ __forceinline__ XYZZ<F> lds_get_xyzz(const uint32_t* slot) {
+    XYZZ<F> r;
+    uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (int i = 0; i < XyzzRegs<F>::COUNT; ++i) d[i] = slot[i];
+    return r;
+}
+
+// ---- 1. digits -----------------------------------------------------------------------------------
+
+struct DigitBias {
+    uint32_t v[13];  // bias limbs (up to 12 + 1)
+};
+
+template <class FrP>
+__global__ void digits_kernel(const uint32_t* __restrict__ scalars, uint32_t n, int c, int nwin, DigitBias bias,
+                              uint16_t* __restrict__ dig) {
+    constexpr int N = FrP::W;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[N + 1];
+    load_words<N>(s, scalars + (size_t)i * N);
+    // Fr::from(BigUint) semantics: reduce below r
+    for (int k = 0; k < 10; ++k) {
+        uint32_t t[N];
+        if (fp_sub_mod_raw<FrP>(t, s)) break;
+#pragma unroll
+        for (int l = 0; l < N; ++l) s[l] = t[l];
+    }
+    uint64_t carry = 0;
+#pragma unroll
+    for (int l = 0; l < N; ++l) {
+        uint64_t t = (uint64_t)s[l] + bias.v[l] + carry;
+        s[l] = (uint32_t)t;
+        carry = t >> 32;
+    }
+    s[N] = (uint32_t)carry + bias.v[N];
+    const uint32_t mask = (1u << c) - 1;
+    for (int w = 0; w < nwin; ++w) {
+        int bit = w * c;
+        int word = bit >> 5, off = bit & 31;
+        uint64_t two = (uint64_t)s[word];
+        if (word + 1 <= N) two |= (uint64_t)s[word + 1] << 32;
+        uint32_t u = (uint32_t)(two >> off) & mask;
+        dig[(size_t)w * n + i] = (uint16_t)u;
+    }
+}
+
+// ---- 2. histogram / 4. scatter ---------------------------------------------------------------------
+
+constexpr int SORT_THREADS = 1024;
+
+static __global__ __launch_bounds__(SORT_THREADS) void hist_kernel(const uint16_t* __restrict__ dig, uint32_t n, int c,
+                                                            int w_first, int nchunk, uint32_t chunk_len,
+                                                            uint32_t* __restrict__ hist) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t B = 1u << (c - 1);
+    const int wl = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+    const int w = w_first + wl;
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) lds[b] = 0;
+    __syncthreads();
+    uint32_t lo = chunk * chunk_len, hi = lo + chunk_len;
+    if (hi > n) hi = n;
+    const uint16_t* d = dig + (size_t)w * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+        int v = (int)d[i] - (int)B;
+        if (v != 0) {
+            uint32_t b = (uint32_t)(v < 0 ? -v : v) - 1;
+            atomicAdd(&lds[b], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* out = hist + (size_t)blockIdx.x * B;
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) out[b] = lds[b];
+}
+
+// per bucket key: exclusive prefix over the sub-histograms of its group, total, segment count
+static __global__ void prefix_kernel(uint32_t* __restrict__ hist, int group_size, uint32_t B, uint32_t n_keys,
+                              uint32_t* __restrict__ total) {
+    uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= n_keys) return;
+    uint32_t g = key / B, b = key % B;
+    uint32_t run = 0;
+    for (int h = 0; h < group_size; ++h) {
+        size_t idx = ((size_t)g * group_size + h) * B + b;
+        uint32_t t = hist[idx];
+        hist[idx] = run;
+        run += t;
+    }
+    total[key] = run;
+}
+
+// The sorted entry list is cut into uniform segments of seg_len entries (one lane each), whatever the bucket
+// sizes are.  A "run" is the part of one bucket inside one segment; bucket `key` owns
+//   nruns = 1 + (last_entry / seg_len) - (first_entry / seg_len)   consecutive partial slots.
+static __global__ void runs_kernel(const uint32_t* __restrict__ bucket_start, uint32_t n_keys, uint32_t seg_len,
+                            uint32_t* __restrict__ nruns) {
+    uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= n_keys) return;
+    uint32_t s0 = bucket_start[key], s1 = bucket_start[key + 1];
+    nruns[key] = s1 > s0 ? 1 + (s1 - 1) / seg_len - s0 / seg_len : 0;
+}
+
+// two-level exclusive scan: blocks of 1024
+constexpr int SCAN_BLOCK = 1024;
+static __global__ __launch_bounds__(SCAN_BLOCK) void scan_block_kernel(const uint32_t* __restrict__ in, uint32_t n,
+                                                                uint32_t* __restrict__ out, uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t sh[SCAN_BLOCK];
+    uint32_t i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    uint32_t v = i < n ? in[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+        uint32_t t = threadIdx.x >= (uint32_t)off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (i < n) out[i] = sh[threadIdx.x] - v;  // exclusive
+    if (threadIdx.x == SCAN_BLOCK - 1) block_sums[blockIdx.x] = sh[threadIdx.x];
+}
+// single block: exclusive scan of the block sums in place (n_blocks <= 1024 * 64)
+static __global__ __launch_bounds__(SCAN_BLOCK) void scan_sums_kernel(uint32_t* sums, uint32_t n_blocks, uint32_t* grand_total) {
+    __shared__ uint32_t sh[SCAN_BLOCK];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_blocks; base += SCAN_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < n_blocks ? sums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+            uint32_t t = threadIdx.x >= (uint32_t)off ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_blocks) sums[i] = carry + sh[threadIdx.x] - v;
+        uint32_t blk_total = sh[SCAN_BLOCK - 1];
+        __syncthreads();
+        carry += blk_total;
+    }
+    if (threadIdx.x == 0) *grand_total = carry;
+}
+static __global__ void scan_add_kernel(uint32_t* out, uint32_t n, const uint32_t* block_sums, const uint32_t* grand_total) {
+    uint32_t i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    if (i < n) out[i] += block_sums[blockIdx.x];
+    if (i == 0) out[n] = *grand_total;  // out has n + 1 entries
+}
+
+static __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const uint16_t* __restrict__ dig, uint32_t n, int c,
+                                                               int w_first, int nchunk, uint32_t chunk_len, int shared_buckets,
+                                                               const uint32_t* __restrict__ hist,
+                                                               const uint32_t* __restrict__ bucket_start,
+                                                               uint32_t* __restrict__ sorted) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t B = 1u << (c - 1);
+    const int wl = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+    const int w = w_first + wl;
+    const uint32_t* pre = hist + (size_t)blockIdx.x * B;
+    const uint32_t* start = bucket_start + (shared_buckets ? 0 : (size_t)wl * B);
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) lds[b] = start[b] + pre[b];
+    __syncthreads();
+    uint32_t lo = chunk * chunk_len, hi = lo + chunk_len;
+    if (hi > n) hi = n;
+    const uint16_t* d = dig + (size_t)w * n;
+    // with shared buckets the point reference addresses the precomputed table row (w, i)
+    const uint32_t ref_base = shared_buckets ? (uint32_t)w * n : 0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+        int v = (int)d[i] - (int)B;
+        if (v != 0) {
+            uint32_t b = (uint32_t)(v < 0 ? -v : v) - 1;
+            uint32_t pos = atomicAdd(&lds[b], 1u);
+            sorted[pos] = (ref_base + i) | (v < 0 ? 0x80000000u : 0u);
+        }
+    }
+}
+
+// ---- 5. accumulate (dominant kernel) ----------------------------------------------------------------
+
+template <class G>
+__global__ __launch_bounds__(256) void accumulate_kernel(const uint32_t* __restrict__ bases,
+                                                         const uint32_t* __restrict__ sorted,
+                                                         const uint32_t* __restrict__ bucket_start,
+                                                         const uint32_t* __restrict__ run_start, uint32_t n_keys,
+                                                         uint32_t seg_len, uint32_t* __restrict__ partials) {
+    typedef typename G::F F;
+    constexpr int AW = 2 * F::LIMBS;
+    constexpr int XW = 4 * F::LIMBS;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = bucket_start[n_keys];
+    const uint32_t begin = t * seg_len;
+    if (begin >= total) return;
+    uint32_t end = begin + seg_len;
+    if (end > total) end = total;
+    // bucket of the first entry: largest key with bucket_start[key] <= begin (its end is > begin)
+    uint32_t lo = 0, hi = n_keys;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (bucket_start[mid] <= begin) lo = mid; else hi = mid;
+    }
+    uint32_t key = lo;
+    uint32_t next = bucket_start[key + 1];
+    XYZZ<F> acc = xyzz_inf<F>();
+    for (uint32_t e = begin; e < end; ++e) {
+        if (e == next) {
+            // the bucket ends inside this segment: flush its run, move to the next non-empty bucket
+            store_xyzz<F>(partials + (size_t)(run_start[key] + t - bucket_start[key] / seg_len) * XW, acc);
+            acc = xyzz_inf<F>();
+            do {
+                ++key;
+                next = bucket_start[key + 1];
+            } while (next <= e);
+        }
+        uint32_t ref = sorted[e];
+        const uint32_t* src = bases + (size_t)(ref & 0x7FFFFFFFu) * AW;
+        xyzz_add_affine_mem<F>(acc, src, (ref >> 31) != 0);
+    }
+    store_xyzz<F>(partials + (size_t)(run_start[key] + t - bucket_start[key] / seg_len) * XW, acc);
+}
+
+// ---- 6. combine ---------------------------------------------------------------------------------
+
+template <class G>
+__global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict__ partials,
+                                                      const uint32_t* __restrict__ seg_start, uint32_t n_keys,
+                                                      uint32_t* __restrict__ buckets) {
+    typedef typename G::F F;
+    constexpr int XW = 4 * F::LIMBS;
+    uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= n_keys) return;
+    uint32_t s0 = seg_start[key], s1 = seg_start[key + 1];
+    XYZZ<F> acc = xyzz_inf<F>();
+    if (s1 > s0) acc = load_xyzz<F>(partials + (size_t)s0 * XW);
+    for (uint32_t s = s0 + 1; s < s1; ++s) acc = xyzz_add<F>(acc, load_xyzz<F>(partials + (size_t)s * XW));
+    store_xyzz<F>(buckets + (size_t)key * XW, acc);
+}
+
+// ---- 7. bucket reduction ----------------------------------------------------------------------------
+
+// Two strided sums in one launch (rows and columns run side by side: the stage is latency-bound, few waves):
+//   out[o] = sum_{j < count} in[(o / per_group) * group_stride + (o % per_group) * outer + j * inner]
+// one wave per output element; lanes stride over j, then a 6-level shuffle tree.
+struct SumJob {
+    uint32_t n_out, per_group, group_stride, outer, inner, count;
+    uint32_t out_offset;  // in points, into the shared output array
+};
+
+template <class G>
+__global__ __launch_bounds__(256) void strided_sum_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                          SumJob j0, SumJob j1) {
+    typedef typename G::F F;
+    constexpr int XW = 4 * F::LIMBS;
+    uint32_t o = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t lane = threadIdx.x & 63;
+    SumJob job = j0;
+    if (o >= j0.n_out) {
+        o -= j0.n_out;
+        job = j1;
+    }
+    if (o >= job.n_out) return;  // whole wave exits together
+    size_t base = (size_t)(o / job.per_group) * job.group_stride + (size_t)(o % job.per_group) * job.outer;
+    XYZZ<F> acc = xyzz_inf<F>();
+    for (uint32_t j = lane; j < job.count; j += 64) {
+        XYZZ<F> p = load_xyzz<F>(in + (base + (size_t)j * job.inner) * XW);
+        acc = xyzz_add<F>(acc, p);
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        XYZZ<F> other = shfl_xor_xyzz<F>(acc, m);
+        acc = xyzz_add<F>(acc, other);
+    }
+    if (lane == 0) store_xyzz<F>(out + ((size_t)job.out_offset + o) * XW, acc);
+}
+
+// one workgroup per array of m <= 256 points: S = sum_j j * X_j and T = sum_j X_j
+// via an inclusive suffix scan (log m steps) followed by a tree sum of the suffixes 1..m-1.
+// Blocks [0, n0) take arrays of m0 points from in0, blocks [n0, ..) arrays of m1 points from in1.
+constexpr int HS_THREADS = 256;
+template <class G>
+__global__ __launch_bounds__(HS_THREADS) void weighted_sum_kernel(const uint32_t* __restrict__ in0, uint32_t m0, uint32_t n0,
+                                                                  const uint32_t* __restrict__ in1, uint32_t m1,
+                                                                  uint32_t* __restrict__ out) {
+    typedef typename G::F F;
+    constexpr int XW = 4 * F::LIMBS;
+    constexpr int RW = XyzzRegs<F>::COUNT;
+    __shared__ uint32_t sh[HS_THREADS * RW];
+    const uint32_t j = threadIdx.x;
+    const bool first = blockIdx.x < n0;
+    const uint32_t m = first ? m0 : m1;
+    const uint32_t* arr = first ? in0 + (size_t)blockIdx.x * m0 * XW : in1 + (size_t)(blockIdx.x - n0) * m1 * XW;
+    XYZZ<F> v = j < m ? load_xyzz<F>(arr + (size_t)j * XW) : xyzz_inf<F>();
+    for (uint32_t off = 1; off < m; off <<= 1) {
+        lds_put_xyzz<F>(sh + (size_t)j * RW, v);
+        __syncthreads();
+        if (j + off < m) {
+            XYZZ<F> o = lds_get_xyzz<F>(sh + (size_t)(j + off) * RW);
+            v = xyzz_add<F>(v, o);
+        }
+        __syncthreads();
+    }
+    // v = suffix sum s_j
+    if (j == 0) store_xyzz<F>(out + ((size_t)blockIdx.x * 2 + 1) * XW, v);  // T = s_0
+    if (j == 0 || j >= m) v = xyzz_inf<F>();
+    uint32_t top = 1;
+    while (top < m) top <<= 1;
+    for (uint32_t off = top / 2; off >= 1; off >>= 1) {
+        lds_put_xyzz<F>(sh + (size_t)j * RW, v);
+        __syncthreads();
+        if (j < off) {
+            XYZZ<F> o = lds_get_xyzz<F>(sh + (size_t)(j + off) * RW);
+            v = xyzz_add<F>(v, o);
+        }
+        __syncthreads();
+    }
+    if (j == 0) store_xyzz<F>(out + (size_t)blockIdx.x * 2 * XW, v);  // S
+}
+
+// ---- bases: canonical -> Montgomery; batch scalar multiplication -------------------------------------
+
+template <class G>
+__global__ void bases_to_mont_kernel(const uint32_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ out) {
+    typedef typename G::F F;
+    constexpr int AW = 2 * F::LIMBS;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[AW];
+    load_words<AW>(w, in + i * AW);
+    Affine<F> p;
+    p.x = F::from_canonical(w);
+    p.y = F::from_canonical(w + F::LIMBS);
+    store_affine<F>(out + i * AW, p);
+}
+
+// out[i] = k_i * P_i (affine, canonical).  broadcast: one base for all.
+template <class G>
+__global__ __launch_bounds__(128) void batch_mul_kernel(const uint32_t* __restrict__ scalars,
+                                                        const uint32_t* __restrict__ bases, int broadcast, uint64_t n,
+                                                        uint32_t* __restrict__ out) {
+    typedef typename G::F F;
+    typedef typename G::Fr FrP;
+    constexpr int AW = 2 * F::LIMBS;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k[FrP::W];
+    load_words<FrP::W>(k, scalars + i * FrP::W);
+    for (int r = 0; r < 10; ++r) {
+        uint32_t t[FrP::W];
+        if (fp_sub_mod_raw<FrP>(t, k)) break;
+#pragma unroll
+        for (int l = 0; l < FrP::W; ++l) k[l] = t[l];
+    }
+    uint32_t w[AW];
+    load_words<AW>(w, bases + (broadcast ? 0 : i * AW));
+    Affine<F> p;
+    p.x = F::from_canonical(w);
+    p.y = F::from_canonical(w + F::LIMBS);
+    XYZZ<F> acc = xyzz_scalar_mul<F>(p, k, FrP::W);
+    Affine<F> a = xyzz_to_affine<F>(acc);
+    F::to_canonical(w, a.x);
+    F::to_canonical(w + F::LIMBS, a.y);
+    store_words<AW>(out + i * AW, w);
+}
+
+// ---- host: plan --------------------------------------------------------------------------------------
+
+static int pick_window_bits(uint64_t n) {
+    // bucket sets must fit the LDS histogram (c <= 16) and stay well filled
+    int lg = log2_u64(n < 2 ? 2 : n);
+    int c = lg - 4;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    return c;
+}
+
+template <class G>
+struct MsmPlan : MsmPlanBase {
+    typedef typename G::F F;
+    typedef typename G::Fr FrP;
+    static constexpr int AW = 2 * F::LIMBS;
+    static constexpr int XW = 4 * F::LIMBS;
+
+    uint64_t n = 0;
+    uint32_t B = 0, R = 0, C = 0;
+    int nchunk = 0;
+    uint32_t chunk_len = 0, seg_len = 0, max_segs = 0;
+    // device buffers
+    uint32_t* d_bases = nullptr;
+    uint32_t* d_scalars = nullptr;
+    uint16_t* d_dig = nullptr;
+    uint32_t *d_hist = nullptr, *d_total = nullptr, *d_nseg = nullptr, *d_bstart = nullptr, *d_sstart = nullptr;
+    uint32_t *d_bsums = nullptr, *d_grand = nullptr;
+    uint32_t *d_sorted = nullptr, *d_partials = nullptr, *d_buckets = nullptr, *d_rows = nullptr, *d_cols = nullptr,
+             *d_final = nullptr;
+    uint32_t* h_final = nullptr;  // pinned
+    hipEvent_t ev[5];
+    bool have_events = false;
+
+    ~MsmPlan() override {
+        void* bufs[] = {d_bases, d_scalars, d_dig, d_hist, d_total, d_nseg, d_bstart, d_sstart, d_bsums, d_grand,
+                        d_sorted, d_partials, d_buckets, d_rows, d_cols, d_final};
+        for (void* b : bufs) if (b) (void)hipFree(b);
+        if (h_final) (void)hipHostFree(h_final);
+        if (have_events) for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+
+    int init(uint64_t n_points, const void* bases, int bases_on_device, int flags, int window_bits) {
+        (void)flags;  // ZK_MSM_PRECOMPUTE: not built yet, the general path is used
+        if (n_points == 0 || n_points > (1ull << 26)) return fail(ZK_ERR_ARG, "MSM size must be in [1, 2^26]");
+        n = n_points;
+        c = window_bits > 0 ? window_bits : pick_window_bits(n);
+        if (c < 2 || c > 16) return fail(ZK_ERR_ARG, "window bits must be in [2, 16]");
+        nwin = (FrP::BITS + 1 + c - 1) / c;
+        B = 1u << (c - 1);
+        int rl = (c - 1 + 1) / 2;
+        if (rl > 8) rl = 8;
+        R = 1u << rl;
+        C = B / R;
+        if (C > 256) return fail(ZK_ERR_ARG, "window too wide for the reduction stage");
+        // chunks: enough workgroups to fill the chip, at most 65535 entries per LDS counter is no issue (u32)
+        nchunk = (int)std::max<uint64_t>(1, std::min<uint64_t>(256 / (uint64_t)std::max(1, nwin) + 1, (n + 4095) / 4096));
+        chunk_len = (uint32_t)((n + nchunk - 1) / nchunk);
+        // segments: aim at >= 4 waves per SIMD worth of lanes
+        uint64_t entries = (uint64_t)nwin * n;
+        uint64_t target = 256ull * 1024;
+        uint64_t sl = (entries + target - 1) / target;
+        if (sl < 8) sl = 8;
+        if (sl > 64) sl = 64;
+        seg_len = (uint32_t)sl;
+        uint64_t n_keys = (uint64_t)nwin * B;
+        uint64_t ms = entries / seg_len + n_keys + 1;
+        if (ms > 0x7FFFFFFFull) return fail(ZK_ERR_ARG, "MSM too large");
+        max_segs = (uint32_t)ms;
+
+        ZK_HIP(hipMalloc(&d_bases, n * AW * 4));
+        if (bases_on_device) {
+            hipLaunchKernelGGL(bases_to_mont_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0,
+                               (const uint32_t*)bases, n, d_bases);
+        } else {
+            uint32_t* tmp = nullptr;
+            ZK_HIP(hipMalloc(&tmp, n * AW * 4));
+            hipError_t e = hipMemcpy(tmp, bases, n * AW * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(bases_to_mont_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, tmp, n, d_bases);
+                e = hipDeviceSynchronize();
+            }
+            (void)hipFree(tmp);
+            ZK_HIP(e);
+        }
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipMalloc(&d_scalars, n * FrP::W * 4));
+        ZK_HIP(hipMalloc(&d_dig, (size_t)nwin * n * 2));
+        ZK_HIP(hipMalloc(&d_hist, (size_t)nwin * nchunk * B * 4));
+        ZK_HIP(hipMalloc(&d_total, n_keys * 4));
+        ZK_HIP(hipMalloc(&d_nseg, n_keys * 4));
+        ZK_HIP(hipMalloc(&d_bstart, (n_keys + 1) * 4));
+        ZK_HIP(hipMalloc(&d_sstart, (n_keys + 1) * 4));
+        ZK_HIP(hipMalloc(&d_bsums, ((n_keys + SCAN_BLOCK - 1) / SCAN_BLOCK + 1) * 4));
+        ZK_HIP(hipMalloc(&d_grand, 4));
+        ZK_HIP(hipMalloc(&d_sorted, entries * 4));
+        ZK_HIP(hipMalloc(&d_partials, (size_t)max_segs * XW * 4));
+        ZK_HIP(hipMalloc(&d_buckets, n_keys * XW * 4));
+        ZK_HIP(hipMalloc(&d_rows, (size_t)nwin * (R + C) * XW * 4));
+        ZK_HIP(hipMalloc(&d_final, (size_t)nwin * 4 * XW * 4));
+        ZK_HIP(hipHostMalloc(&h_final, (size_t)nwin * 4 * XW * 4));
+        for (auto& e : ev) ZK_HIP(hipEventCreate(&e));
+        have_events = true;
+        // LDS above 64 KiB needs the opt-in
+        int lds_bytes = (int)(B * 4);
+        ZK_HIP(hipFuncSetAttribute((const void*)hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        ZK_HIP(hipFuncSetAttribute((const void*)scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        ZK_HIP(hipDeviceSynchronize());
+        return ZK_OK;
+    }
+
+    int exclusive_scan(const uint32_t* in, uint32_t cnt, uint32_t* out, hipStream_t st) {
+        uint32_t blocks = (cnt + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        hipLaunchKernelGGL(scan_block_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, st, in, cnt, out, d_bsums);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, d_bsums, blocks, d_grand);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, st, out, cnt, d_bsums, d_grand);
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+
+    int run(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count, uint64_t* out,
+            hipStream_t st) override {
+        std::lock_guard<std::mutex> lock(mu);
+        if (n_scalars > n) return fail(ZK_ERR_LENGTH, "Number of points and scalars mismatch");
+        if (w_count <= 0) { w_first = 0; w_count = nwin; }
+        if (w_first < 0 || w_first + w_count > nwin) return fail(ZK_ERR_ARG, "window range out of bounds");
+        const uint32_t m = (uint32_t)n_scalars;
+        XYZZ<F> total = xyzz_inf<F>();
+        if (m > 0) {
+            const uint32_t* sc = (const uint32_t*)scalars;
+            if (!on_device) {
+                ZK_HIP(hipMemcpyAsync(d_scalars, scalars, (size_t)m * FrP::W * 4, hipMemcpyHostToDevice, st));
+                sc = d_scalars;
+            }
+            const uint32_t n_keys = (uint32_t)w_count * B;
+            const uint32_t ch_len = (m + nchunk - 1) / nchunk;
+            ZK_HIP(hipEventRecord(ev[0], st));
+            // 1. digits
+            DigitBias bias;
+            memset(&bias, 0, sizeof(bias));
+            for (int w = 0; w < nwin; ++w) {
+                int bit = w * c + (c - 1);
+                bias.v[bit >> 5] |= 1u << (bit & 31);
+            }
+            hipLaunchKernelGGL(digits_kernel<FrP>, dim3((m + 255) / 256), dim3(256), 0, st, sc, m, c, nwin, bias, d_dig);
+            // 2. histogram
+            hipLaunchKernelGGL(hist_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), B * 4, st, d_dig, m, c, w_first, nchunk, ch_len, d_hist);
+            // 3. prefix + scans
+            hipLaunchKernelGGL(prefix_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_hist, nchunk, B, n_keys, d_total);
+            int rc;
+            if ((rc = exclusive_scan(d_total, n_keys, d_bstart, st))) return rc;
+            hipLaunchKernelGGL(runs_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_bstart, n_keys, seg_len, d_nseg);
+            if ((rc = exclusive_scan(d_nseg, n_keys, d_sstart, st))) return rc;
+            // 4. scatter
+            hipLaunchKernelGGL(scatter_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), B * 4, st, d_dig, m, c, w_first, nchunk, ch_len, 0, d_hist, d_bstart, d_sorted);
+            ZK_HIP(hipEventRecord(ev[1], st));
+            // 5. accumulate
+            uint64_t lanes = ((uint64_t)w_count * m + seg_len - 1) / seg_len;
+            hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, d_bases, d_sorted, d_bstart, d_sstart, n_keys, seg_len, d_partials);
+            ZK_HIP(hipEventRecord(ev[2], st));
+            // 6. combine
+            hipLaunchKernelGGL(combine_kernel<G>, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_partials, d_sstart, n_keys, d_buckets);
+            // 7. reduce: rows (sum over lo), cols (sum over hi), weighted sums
+            uint32_t n_rows = (uint32_t)w_count * R, n_cols = (uint32_t)w_count * C;
+            SumJob rows = {n_rows, R, B, C, 1u, C, 0u};
+            SumJob cols = {n_cols, C, B, 1u, C, R, n_rows};
+            // d_rows holds the row sums followed by the column sums
+            hipLaunchKernelGGL(strided_sum_kernel<G>, dim3(((n_rows + n_cols) * 64 + 255) / 256), dim3(256), 0, st, d_buckets, d_rows, rows, cols);
+            hipLaunchKernelGGL(weighted_sum_kernel<G>, dim3(2 * w_count), dim3(HS_THREADS), 0, st, d_rows, R, (uint32_t)w_count,
+                               d_rows + (size_t)n_rows * XW, C, d_final);
+            ZK_HIP(hipGetLastError());
+            ZK_HIP(hipMemcpyAsync(h_final, d_final, (size_t)w_count * 4 * XW * 4, hipMemcpyDeviceToHost, st));
+            ZK_HIP(hipEventRecord(ev[3], st));
+            ZK_HIP(hipStreamSynchronize(st));
+            // 8. host tail: window sum W = C * S_R + S_C + T ; Horner over windows
+            for (int wl = w_count - 1; wl >= 0; --wl) {
+                const uint32_t* rowp = h_final + (size_t)wl * 2 * XW;
+                const uint32_t* colp = h_final + ((size_t)w_count * 2 + (size_t)wl * 2) * XW;
+                XYZZ<F> sr = load_xyzz_host<F>(rowp), tot = load_xyzz_host<F>(rowp + XW), scol = load_xyzz_host<F>(colp);
+                for (uint32_t k = 1; k < C; k <<= 1) sr = xyzz_dbl<F>(sr);
+                XYZZ<F> wsum = xyzz_add<F>(xyzz_add<F>(sr, scol), tot);
+                if (wl != w_count - 1) for (int k = 0; k < c; ++k) total = xyzz_dbl<F>(total);
+                total = xyzz_add<F>(total, wsum);
+            }
+            for (int k = 0; k < c * w_first; ++k) total = xyzz_dbl<F>(total);
+            ZK_HIP(hipEventRecord(ev[4], st));
+            ZK_HIP(hipEventSynchronize(ev[4]));
+            (void)hipEventElapsedTime(&timings[0], ev[0], ev[1]);
+            (void)hipEventElapsedTime(&timings[1], ev[1], ev[2]);
+            (void)hipEventElapsedTime(&timings[2], ev[2], ev[3]);
+            (void)hipEventElapsedTime(&timings[3], ev[3], ev[4]);
+            (void)hipEventElapsedTime(&timings[4], ev[0], ev[4]);
+        }
+        Affine<F> a = xyzz_to_affine<F>(total);
+        uint32_t w[AW];
+        F::to_canonical(w, a.x);
+        F::to_canonical(w + F::LIMBS, a.y);
+        memcpy(out, w, sizeof(w));
+        return ZK_OK;
+    }
+};
+
+template <class G>
+static int batch_mul_impl(uint64_t n, const uint64_t* scalars, const uint64_t* bases, int broadcast, uint64_t* out) {
+    typedef typename G::F F;
+    typedef typename G::Fr FrP;
+    constexpr int AW = 2 * F::LIMBS;
+    if (n == 0) return ZK_OK;
+    uint32_t *ds = nullptr, *db = nullptr, *dout = nullptr;
+    int rc = ZK_OK;
+    uint64_t nb = broadcast ? 1 : n;
+    ZK_HIP(hipMalloc(&ds, n * FrP::W * 4));
+    do {
+        if (hipMalloc(&db, nb * AW * 4) != hipSuccess || hipMalloc(&dout, n * AW * 4) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMalloc failed"); break; }
+        if (hipMemcpy(ds, scalars, n * FrP::W * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(db, bases, nb * AW * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy H2D failed"); break; }
+        hipLaunchKernelGGL(batch_mul_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, ds, db, broadcast, n, dout);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(out, dout, n * AW * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "batch_mul kernel / D2H failed"); break; }
+    } while (0);
+    (void)hipFree(ds); (void)hipFree(db); (void)hipFree(dout);
+    return rc;
+}
+
+
+}  // namespace zkmi

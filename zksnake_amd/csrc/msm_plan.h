@@ -1,0 +1,30 @@
+// msm_plan.h -- interface between the C API (msm.hip) and the per-group kernel translation units
+// (msm_group.hip compiled once per curve group, so the four instantiations build in parallel).
+#pragma once
+#include <cstdint>
+#include <mutex>
+#include <hip/hip_runtime.h>
+
+namespace zkmi {
+
+struct MsmPlanBase {
+    virtual ~MsmPlanBase() {}
+    virtual int run(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count, uint64_t* out,
+                    hipStream_t stream) = 0;
+    int c = 0, nwin = 0;
+    float timings[5] = {0, 0, 0, 0, 0};
+    std::mutex mu;
+};
+
+
+// factories implemented in msm_group.hip (one object file per group)
+#define ZK_DECLARE_GROUP(G)                                                                                              \
+    int msm_plan_create_##G(uint64_t n, const void* bases, int on_device, int flags, int window_bits, MsmPlanBase** out); \
+    int msm_batch_mul_##G(uint64_t n, const uint64_t* scalars, const uint64_t* bases, int broadcast, uint64_t* out);
+ZK_DECLARE_GROUP(Bn254G1)
+ZK_DECLARE_GROUP(Bn254G2)
+ZK_DECLARE_GROUP(Bls381G1)
+ZK_DECLARE_GROUP(Bls381G2)
+#undef ZK_DECLARE_GROUP
+
+}  // namespace zkmi
