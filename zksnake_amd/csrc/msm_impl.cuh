@@ -199,12 +199,18 @@ static __global__ void prefix_kernel(uint32_t* __restrict__ hist, int group_size
 // The sorted entry list is cut into uniform segments of seg_len entries (one lane each), whatever the bucket
 // sizes are.  A "run" is the part of one bucket inside one segment; bucket `key` owns
 //   nruns = 1 + (last_entry / seg_len) - (first_entry / seg_len)   consecutive partial slots.
+// Buckets with more than COMBINE_SMALL_MAX runs (skewed scalars: e.g. the short top window, or many equal
+// scalars) are listed in big_list and reduced by a whole workgroup each instead of one lane.
+constexpr uint32_t COMBINE_SMALL_MAX = 16;
 static __global__ void runs_kernel(const uint32_t* __restrict__ bucket_start, uint32_t n_keys, uint32_t seg_len,
-                            uint32_t* __restrict__ nruns) {
+                                   uint32_t* __restrict__ nruns, uint32_t* __restrict__ big_list,
+                                   uint32_t* __restrict__ big_count) {
     uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= n_keys) return;
     uint32_t s0 = bucket_start[key], s1 = bucket_start[key + 1];
-    nruns[key] = s1 > s0 ? 1 + (s1 - 1) / seg_len - s0 / seg_len : 0;
+    uint32_t r = s1 > s0 ? 1 + (s1 - 1) / seg_len - s0 / seg_len : 0;
+    nruns[key] = r;
+    if (r > COMBINE_SMALL_MAX) big_list[atomicAdd(big_count, 1u)] = key;
 }
 
 // two-level exclusive scan: blocks of 1024
@@ -328,17 +334,50 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const uint32_t* __restr
 
 template <class G>
 __global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict__ partials,
-                                                      const uint32_t* __restrict__ seg_start, uint32_t n_keys,
+                                                      const uint32_t* __restrict__ run_start, uint32_t n_keys,
                                                       uint32_t* __restrict__ buckets) {
     typedef typename G::F F;
     constexpr int XW = 4 * F::LIMBS;
     uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= n_keys) return;
-    uint32_t s0 = seg_start[key], s1 = seg_start[key + 1];
+    uint32_t s0 = run_start[key], s1 = run_start[key + 1];
+    if (s1 - s0 > COMBINE_SMALL_MAX) return;  // combine_big_kernel owns this bucket
     XYZZ<F> acc = xyzz_inf<F>();
     if (s1 > s0) acc = load_xyzz<F>(partials + (size_t)s0 * XW);
     for (uint32_t s = s0 + 1; s < s1; ++s) acc = xyzz_add<F>(acc, load_xyzz<F>(partials + (size_t)s * XW));
     store_xyzz<F>(buckets + (size_t)key * XW, acc);
+}
+
+// one workgroup per listed bucket: lanes stride over its runs, then a log-depth tree through LDS
+constexpr int BIG_THREADS = 256;
+template <class G>
+__global__ __launch_bounds__(BIG_THREADS) void combine_big_kernel(const uint32_t* __restrict__ partials,
+                                                                  const uint32_t* __restrict__ run_start,
+                                                                  const uint32_t* __restrict__ big_list,
+                                                                  const uint32_t* __restrict__ big_count,
+                                                                  uint32_t* __restrict__ buckets) {
+    typedef typename G::F F;
+    constexpr int XW = 4 * F::LIMBS;
+    constexpr int RW = XyzzRegs<F>::COUNT;
+    __shared__ uint32_t sh[BIG_THREADS * RW];
+    const uint32_t count = *big_count;
+    const uint32_t j = threadIdx.x;
+    for (uint32_t b = blockIdx.x; b < count; b += gridDim.x) {
+        const uint32_t key = big_list[b];
+        const uint32_t s0 = run_start[key], s1 = run_start[key + 1];
+        XYZZ<F> v = xyzz_inf<F>();
+        for (uint32_t s = s0 + j; s < s1; s += BIG_THREADS) v = xyzz_add<F>(v, load_xyzz<F>(partials + (size_t)s * XW));
+        for (uint32_t off = BIG_THREADS / 2; off >= 1; off >>= 1) {
+            lds_put_xyzz<F>(sh + (size_t)j * RW, v);
+            __syncthreads();
+            if (j < off) {
+                XYZZ<F> o = lds_get_xyzz<F>(sh + (size_t)(j + off) * RW);
+                v = xyzz_add<F>(v, o);
+            }
+            __syncthreads();
+        }
+        if (j == 0) store_xyzz<F>(buckets + (size_t)key * XW, v);
+    }
 }
 
 // ---- 7. bucket reduction ----------------------------------------------------------------------------
@@ -493,7 +532,7 @@ struct MsmPlan : MsmPlanBase {
     uint32_t* d_scalars = nullptr;
     uint16_t* d_dig = nullptr;
     uint32_t *d_hist = nullptr, *d_total = nullptr, *d_nseg = nullptr, *d_bstart = nullptr, *d_sstart = nullptr;
-    uint32_t *d_bsums = nullptr, *d_grand = nullptr;
+    uint32_t *d_bsums = nullptr, *d_grand = nullptr, *d_big_list = nullptr, *d_big_count = nullptr;
     uint32_t *d_sorted = nullptr, *d_partials = nullptr, *d_buckets = nullptr, *d_rows = nullptr, *d_cols = nullptr,
              *d_final = nullptr;
     uint32_t* h_final = nullptr;  // pinned
@@ -501,7 +540,7 @@ struct MsmPlan : MsmPlanBase {
     bool have_events = false;
 
     ~MsmPlan() override {
-        void* bufs[] = {d_bases, d_scalars, d_dig, d_hist, d_total, d_nseg, d_bstart, d_sstart, d_bsums, d_grand,
+        void* bufs[] = {d_bases, d_scalars, d_dig, d_hist, d_total, d_nseg, d_bstart, d_sstart, d_bsums, d_grand, d_big_list, d_big_count,
                         d_sorted, d_partials, d_buckets, d_rows, d_cols, d_final};
         for (void* b : bufs) if (b) (void)hipFree(b);
         if (h_final) (void)hipHostFree(h_final);
@@ -561,6 +600,8 @@ struct MsmPlan : MsmPlanBase {
         ZK_HIP(hipMalloc(&d_sstart, (n_keys + 1) * 4));
         ZK_HIP(hipMalloc(&d_bsums, ((n_keys + SCAN_BLOCK - 1) / SCAN_BLOCK + 1) * 4));
         ZK_HIP(hipMalloc(&d_grand, 4));
+        ZK_HIP(hipMalloc(&d_big_list, n_keys * 4));
+        ZK_HIP(hipMalloc(&d_big_count, 4));
         ZK_HIP(hipMalloc(&d_sorted, entries * 4));
         ZK_HIP(hipMalloc(&d_partials, (size_t)max_segs * XW * 4));
         ZK_HIP(hipMalloc(&d_buckets, n_keys * XW * 4));
@@ -617,7 +658,8 @@ struct MsmPlan : MsmPlanBase {
             hipLaunchKernelGGL(prefix_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_hist, nchunk, B, n_keys, d_total);
             int rc;
             if ((rc = exclusive_scan(d_total, n_keys, d_bstart, st))) return rc;
-            hipLaunchKernelGGL(runs_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_bstart, n_keys, seg_len, d_nseg);
+            ZK_HIP(hipMemsetAsync(d_big_count, 0, 4, st));
+            hipLaunchKernelGGL(runs_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_bstart, n_keys, seg_len, d_nseg, d_big_list, d_big_count);
             if ((rc = exclusive_scan(d_nseg, n_keys, d_sstart, st))) return rc;
             // 4. scatter
             hipLaunchKernelGGL(scatter_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), B * 4, st, d_dig, m, c, w_first, nchunk, ch_len, 0, d_hist, d_bstart, d_sorted);
@@ -628,6 +670,7 @@ struct MsmPlan : MsmPlanBase {
             ZK_HIP(hipEventRecord(ev[2], st));
             // 6. combine
             hipLaunchKernelGGL(combine_kernel<G>, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_partials, d_sstart, n_keys, d_buckets);
+            hipLaunchKernelGGL(combine_big_kernel<G>, dim3(256), dim3(BIG_THREADS), 0, st, d_partials, d_sstart, d_big_list, d_big_count, d_buckets);
             // 7. reduce: rows (sum over lo), cols (sum over hi), weighted sums
             uint32_t n_rows = (uint32_t)w_count * R, n_cols = (uint32_t)w_count * C;
             SumJob rows = {n_rows, R, B, C, 1u, C, 0u};
