@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra", action="store_true", help="also time NTT 2^22 and report it under 'extra'")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -55,12 +57,18 @@ def main():
     import torch
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, n_dev)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-    lib = N.ensure_gpu(local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    lib = N.ensure_gpu(dev_index)
+    gather_dev = dev if args.backend == "nccl" else None
 
     cid, grp = N.CURVE_BN254, N.G1
     r = constant.BN254_SCALAR_FIELD
@@ -98,7 +106,7 @@ def main():
             out[:] = 0
         if world == 1:
             return out.copy()
-        return all_gather_sum(cid, grp, out, dev)
+        return all_gather_sum(cid, grp, out, gather_dev)
 
     def sync():
         torch.cuda.synchronize()
@@ -123,7 +131,7 @@ def main():
     if not (res == expected).all():
         raise SystemExit("MSM result changed during the timed loop")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
