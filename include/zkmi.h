@@ -129,6 +129,15 @@ int zk_msm_plan_destroy(uint64_t handle);
  * add up to the full MSM. */
 int zk_msm_plan_run(uint64_t handle, uint64_t n_scalars, const void* scalars, int scalars_on_device,
                     int window_first, int window_count, uint64_t* out, void* stream);
+/* Asynchronous form: enqueue puts all GPU stages and the D2H copy of the per-window results on the
+ * stream and returns; finish waits and runs the host tail.  One run may be in flight per plan.
+ * ZK_STREAM_PLAN selects a stream owned by the plan, so several plans (the five MSMs of a Groth16 proof)
+ * overlap: their latency-bound reduction stages hide behind other plans' accumulation kernels.  Plan streams
+ * are ordinary blocking streams: they are ordered after earlier work on the NULL stream. */
+#define ZK_STREAM_PLAN ((void*)(intptr_t)-1)
+int zk_msm_plan_enqueue(uint64_t handle, uint64_t n_scalars, const void* scalars, int scalars_on_device,
+                        int window_first, int window_count, void* stream);
+int zk_msm_plan_finish(uint64_t handle, uint64_t* out);
 int zk_msm_plan_windows(uint64_t handle, int* window_bits, int* n_windows);
 /* milliseconds of the stages of the last zk_msm_plan_run on this plan, measured with HIP events on
  * the launch stream: [0] digits+sort, [1] bucket accumulation (dominant kernel), [2] bucket reduction,

@@ -56,8 +56,7 @@ class PointArray:
         self.curve_id = curve_id
         self.group = group
         self.limbs = np.ascontiguousarray(limbs, dtype=np.uint64).reshape(-1, N.point_limbs(curve_id, group))
-        self._plan = None
-        self._plan_n = 0
+        self._plans = {}
 
     def __len__(self):
         return self.limbs.shape[0]
@@ -75,19 +74,20 @@ class PointArray:
     def to_list(self):
         return list(self)
 
-    def plan(self):
-        """device-resident bases + workspace (created on first use)"""
-        if self._plan is None:
+    def plan(self, slot=0):
+        """device-resident bases + workspace (created on first use).  A second slot gives an independent
+        workspace so two MSMs over the same key (tau_1 with u and with v) can be in flight together."""
+        if slot not in self._plans:
             lib = N.ensure_gpu()
             h = N._u64(0)
             N.check(lib.zk_msm_plan_create(self.curve_id, self.group, len(self), self.limbs.ctypes.data, 0, 0, 0, h))
-            self._plan = h.value
-        return self._plan
+            self._plans[slot] = h.value
+        return self._plans[slot]
 
     def release(self):
-        if self._plan is not None:
-            N.load().zk_msm_plan_destroy(self._plan)
-            self._plan = None
+        for h in self._plans.values():
+            N.load().zk_msm_plan_destroy(h)
+        self._plans = {}
 
     def __del__(self):
         try:

@@ -29,6 +29,7 @@ G1 = 1
 G2 = 2
 
 MSM_PRECOMPUTE = 1
+STREAM_PLAN = ctypes.c_void_p(-1)  # ZK_STREAM_PLAN: the plan's own stream
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -63,6 +64,8 @@ SIGNATURES = {
     "zk_msm_plan_create": (_i, [_i, _i, _u64, _vp, _i, _i, _i, _u64p]),
     "zk_msm_plan_destroy": (_i, [_u64]),
     "zk_msm_plan_run": (_i, [_u64, _u64, _vp, _i, _i, _i, _u64p, _vp]),
+    "zk_msm_plan_enqueue": (_i, [_u64, _u64, _vp, _i, _i, _i, _vp]),
+    "zk_msm_plan_finish": (_i, [_u64, _u64p]),
     "zk_msm_plan_windows": (_i, [_u64, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "zk_msm_plan_timings": (_i, [_u64, ctypes.POINTER(ctypes.c_float), _i]),
     "zk_point_add": (_i, [_i, _i, _u64p, _u64p, _u64p]),

@@ -60,11 +60,28 @@ static MsmPlanBase* find_plan(uint64_t handle) {
     return it == g_plans.end() ? nullptr : it->second;
 }
 
+static hipStream_t pick_stream(MsmPlanBase* p, void* stream) {
+    return stream == ZK_STREAM_PLAN ? p->own_stream : (hipStream_t)stream;
+}
+
 int zk_msm_plan_run(uint64_t handle, uint64_t n_scalars, const void* scalars, int scalars_on_device, int window_first,
                     int window_count, uint64_t* out, void* stream) {
     MsmPlanBase* p = find_plan(handle);
     if (!p) return fail(ZK_ERR_ARG, "unknown MSM plan handle");
-    return p->run(n_scalars, scalars, scalars_on_device, window_first, window_count, out, (hipStream_t)stream);
+    return p->run(n_scalars, scalars, scalars_on_device, window_first, window_count, out, pick_stream(p, stream));
+}
+
+int zk_msm_plan_enqueue(uint64_t handle, uint64_t n_scalars, const void* scalars, int scalars_on_device, int window_first,
+                        int window_count, void* stream) {
+    MsmPlanBase* p = find_plan(handle);
+    if (!p) return fail(ZK_ERR_ARG, "unknown MSM plan handle");
+    return p->enqueue(n_scalars, scalars, scalars_on_device, window_first, window_count, pick_stream(p, stream));
+}
+
+int zk_msm_plan_finish(uint64_t handle, uint64_t* out) {
+    MsmPlanBase* p = find_plan(handle);
+    if (!p) return fail(ZK_ERR_ARG, "unknown MSM plan handle");
+    return p->finish(out);
 }
 
 int zk_msm_plan_windows(uint64_t handle, int* window_bits, int* n_windows) {

@@ -545,6 +545,7 @@ struct MsmPlan : MsmPlanBase {
         for (void* b : bufs) if (b) (void)hipFree(b);
         if (h_final) (void)hipHostFree(h_final);
         if (have_events) for (auto& e : ev) (void)hipEventDestroy(e);
+        if (own_stream) (void)hipStreamDestroy(own_stream);
     }
 
     int init(uint64_t n_points, const void* bases, int bases_on_device, int flags, int window_bits) {
@@ -610,6 +611,7 @@ struct MsmPlan : MsmPlanBase {
         ZK_HIP(hipHostMalloc(&h_final, (size_t)nwin * 4 * XW * 4));
         for (auto& e : ev) ZK_HIP(hipEventCreate(&e));
         have_events = true;
+        ZK_HIP(hipStreamCreate(&own_stream));
         // LDS above 64 KiB needs the opt-in
         int lds_bytes = (int)(B * 4);
         ZK_HIP(hipFuncSetAttribute((const void*)hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
@@ -627,14 +629,20 @@ struct MsmPlan : MsmPlanBase {
         return ZK_OK;
     }
 
-    int run(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count, uint64_t* out,
-            hipStream_t st) override {
+    // state carried from enqueue() to finish()
+    int q_first = 0, q_count = 0;
+    uint32_t q_m = 0;
+    hipStream_t q_stream = nullptr;
+    bool q_pending = false;
+
+    int enqueue(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count, hipStream_t st) override {
         std::lock_guard<std::mutex> lock(mu);
+        if (q_pending) return fail(ZK_ERR_ARG, "MSM plan already has a run in flight: call zk_msm_plan_finish first");
         if (n_scalars > n) return fail(ZK_ERR_LENGTH, "Number of points and scalars mismatch");
         if (w_count <= 0) { w_first = 0; w_count = nwin; }
         if (w_first < 0 || w_first + w_count > nwin) return fail(ZK_ERR_ARG, "window range out of bounds");
         const uint32_t m = (uint32_t)n_scalars;
-        XYZZ<F> total = xyzz_inf<F>();
+        q_first = w_first; q_count = w_count; q_m = m; q_stream = st;
         if (m > 0) {
             const uint32_t* sc = (const uint32_t*)scalars;
             if (!on_device) {
@@ -682,7 +690,19 @@ struct MsmPlan : MsmPlanBase {
             ZK_HIP(hipGetLastError());
             ZK_HIP(hipMemcpyAsync(h_final, d_final, (size_t)w_count * 4 * XW * 4, hipMemcpyDeviceToHost, st));
             ZK_HIP(hipEventRecord(ev[3], st));
-            ZK_HIP(hipStreamSynchronize(st));
+        }
+        q_pending = true;
+        return ZK_OK;
+    }
+
+    int finish(uint64_t* out) override {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!q_pending) return fail(ZK_ERR_ARG, "zk_msm_plan_finish without a pending run");
+        q_pending = false;
+        const int w_first = q_first, w_count = q_count;
+        XYZZ<F> total = xyzz_inf<F>();
+        if (q_m > 0) {
+            ZK_HIP(hipEventSynchronize(ev[3]));
             // 8. host tail: window sum W = C * S_R + S_C + T ; Horner over windows
             for (int wl = w_count - 1; wl >= 0; --wl) {
                 const uint32_t* rowp = h_final + (size_t)wl * 2 * XW;
@@ -694,7 +714,7 @@ struct MsmPlan : MsmPlanBase {
                 total = xyzz_add<F>(total, wsum);
             }
             for (int k = 0; k < c * w_first; ++k) total = xyzz_dbl<F>(total);
-            ZK_HIP(hipEventRecord(ev[4], st));
+            ZK_HIP(hipEventRecord(ev[4], q_stream));
             ZK_HIP(hipEventSynchronize(ev[4]));
             (void)hipEventElapsedTime(&timings[0], ev[0], ev[1]);
             (void)hipEventElapsedTime(&timings[1], ev[1], ev[2]);

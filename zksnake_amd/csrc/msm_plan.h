@@ -9,8 +9,17 @@ namespace zkmi {
 
 struct MsmPlanBase {
     virtual ~MsmPlanBase() {}
-    virtual int run(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count, uint64_t* out,
-                    hipStream_t stream) = 0;
+    // enqueue() puts every GPU stage plus the D2H copy of the per-window results on `stream` and returns;
+    // finish() waits for them and runs the host tail.  run() = enqueue() + finish().
+    virtual int enqueue(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count,
+                        hipStream_t stream) = 0;
+    virtual int finish(uint64_t* out) = 0;
+    int run(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count, uint64_t* out,
+            hipStream_t stream) {
+        int rc = enqueue(n_scalars, scalars, on_device, w_first, w_count, stream);
+        return rc ? rc : finish(out);
+    }
+    hipStream_t own_stream = nullptr;  // used when the caller passes ZK_STREAM_PLAN
     int c = 0, nwin = 0;
     float timings[5] = {0, 0, 0, 0, 0};
     std::mutex mu;

@@ -87,15 +87,21 @@ class Groth16:
         self.verifying_key = VerifyingKey(alpha_G1, beta_G2, gamma_G2, delta_G2, k_gamma_G1)
 
     # ------------------------------------------------------------------------------------------
-    def _msm_dev(self, bases, group, d_scalars, count):
-        """<bases[:count], scalars> with scalars already in HBM"""
+    def _enqueue_msm(self, bases, group, d_scalars, count, slot=0):
+        """start <bases[:count], scalars> (scalars already in HBM) on the plan's own stream"""
+        lib = N.load()
+        arr = _as_array(self.E, bases, group)
+        handle = arr.plan(slot)
+        N.check(lib.zk_msm_plan_enqueue(handle, count, d_scalars, 1, 0, 0, N.STREAM_PLAN))
+        return arr, handle
+
+    def _finish_msm(self, handle, group):
         lib = N.load()
         cid = self.E.curve.curve_id
-        arr = _as_array(self.E, bases, group)
         out = np.zeros(N.point_limbs(cid, group), dtype=np.uint64)
-        N.check(lib.zk_msm_plan_run(arr.plan(), count, d_scalars, 1, 0, 0, N.u64p(out), None))
+        N.check(lib.zk_msm_plan_finish(handle, N.u64p(out)))
         from .._algebra import _point_class
-        return arr, _point_class(cid, group)._from_limbs(out)
+        return _point_class(cid, group)._from_limbs(out)
 
     def prove(self, public_witness, private_witness) -> Proof:
         """public_witness / private_witness: lists of ints (reference API) or (k, 4) uint64 limb arrays."""
@@ -122,21 +128,25 @@ class Groth16:
         n = res.n
         n_pub = self.qap.n_public
         n_priv = len(private_witness)
-        pk.tau_1, msm_u = self._msm_dev(pk.tau_1, 1, res.u.ptr, min(n, len(pk.tau_1)))
-        pk.tau_1, msm_v1 = self._msm_dev(pk.tau_1, 1, res.v.ptr, min(n, len(pk.tau_1)))
-        pk.tau_2, msm_v2 = self._msm_dev(pk.tau_2, 2, res.v.ptr, min(n, len(pk.tau_2)))
-        pk.target_1, HZ = self._msm_dev(pk.target_1, 1, res.h.ptr, min(n, len(pk.target_1)))
+        # all five MSMs are put in flight on their plans' own streams, then collected: the latency-bound
+        # bucket reductions of one overlap with the accumulation kernels of the others
+        pk.tau_1, h_u = self._enqueue_msm(pk.tau_1, 1, res.u.ptr, min(n, len(pk.tau_1)), slot=0)
+        pk.tau_2, h_v2 = self._enqueue_msm(pk.tau_2, 2, res.v.ptr, min(n, len(pk.tau_2)))
+        pk.tau_1, h_v1 = self._enqueue_msm(pk.tau_1, 1, res.v.ptr, min(n, len(pk.tau_1)), slot=1)
+        pk.target_1, h_h = self._enqueue_msm(pk.target_1, 1, res.h.ptr, min(n, len(pk.target_1)))
+        h_k = None
         if n_priv > 0:
-            pk.kdelta_1, sum_delta_witness = self._msm_dev(pk.kdelta_1, 1, res.witness.ptr + 32 * n_pub, n_priv)
-        else:
-            sum_delta_witness = self.E.G1() * 0
+            pk.kdelta_1, h_k = self._enqueue_msm(pk.kdelta_1, 1, res.witness.ptr + 32 * n_pub, n_priv)
+        msm_u = self._finish_msm(h_u, 1)
+        msm_v2 = self._finish_msm(h_v2, 2)
+        msm_v1 = self._finish_msm(h_v1, 1)
+        HZ = self._finish_msm(h_h, 1)
+        sum_delta_witness = self._finish_msm(h_k, 1) if h_k is not None else self.E.G1() * 0
 
         A = msm_u + pk.alpha_1 + pk.delta_1 * r
         B1 = msm_v1 + pk.beta_1 + pk.delta_1 * s
         B2 = msm_v2 + pk.beta_2 + pk.delta_2 * s
         C = HZ + sum_delta_witness + A * s + B1 * r + (-pk.delta_1) * (r * s % q)
-        for buf in (res.u, res.v, res.h, res.witness):
-            buf.free()
         return Proof(A, B2, C)
 
     # ------------------------------------------------------------------------------------------

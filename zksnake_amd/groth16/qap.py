@@ -37,6 +37,7 @@ class QAP:
         self.n_public = 0
         self.p = p or BN254_SCALAR_FIELD
         self._dev = None
+        self._ws = None
 
     def from_r1cs(self, r1cs):
         assert r1cs.A is not None, "R1CS is not compiled"
@@ -61,9 +62,19 @@ class QAP:
             self._dev = mats
         return self._dev
 
+    def _workspace(self, n, n_col):
+        """device buffers reused across proofs (hipMalloc / hipFree are synchronous and slow)"""
+        key = (n, n_col)
+        if self._ws is None or self._ws[0] != key:
+            eb = 32
+            self._ws = (key, dict(w=DeviceBuffer(n_col * eb), a=DeviceBuffer(n * eb), b=DeviceBuffer(n * eb),
+                                  c=DeviceBuffer(n * eb), h=DeviceBuffer(n * eb), work=DeviceBuffer(4 * n * eb)))
+        return self._ws[1]
+
     def evaluate_witness_device(self, witness) -> DeviceQapResult:
         """witness: list of ints or (n_col, 4) uint64 limbs.  Raises ValueError when the witness does
-        not satisfy the constraints (non-zero remainder), like the reference."""
+        not satisfy the constraints (non-zero remainder), like the reference.  The returned buffers belong
+        to this QAP object and are overwritten by the next call."""
         lib = N.ensure_gpu()
         cid = self._curve_id()
         n = self.a.n_row
@@ -73,20 +84,15 @@ class QAP:
         w_limbs = witness if isinstance(witness, np.ndarray) else N.ints_to_limbs(witness, 4, self.p)
         if w_limbs.shape[0] != self.a.n_col:
             raise ValueError("witness length does not match the number of R1CS columns")
-        d_w = DeviceBuffer.from_numpy(w_limbs)
-        eb = 32
-        d_a, d_b, d_c = DeviceBuffer(n * eb), DeviceBuffer(n * eb), DeviceBuffer(n * eb)
-        for (rp, cl, vl), dst in zip(self._device_matrices(), (d_a, d_b, d_c)):
-            N.check(lib.zk_spmv_dev(cid, n, rp.ptr, cl.ptr, vl.ptr, d_w.ptr, dst.ptr, None))
-        d_h = DeviceBuffer(n * eb)
-        d_work = DeviceBuffer(4 * n * eb)
+        ws = self._workspace(n, self.a.n_col)
+        ws["w"].upload(w_limbs)
+        for (rp, cl, vl), dst in zip(self._device_matrices(), (ws["a"], ws["b"], ws["c"])):
+            N.check(lib.zk_spmv_dev(cid, n, rp.ptr, cl.ptr, vl.ptr, ws["w"].ptr, dst.ptr, None))
         ok = N._i(0)
-        N.check(lib.zk_qap_h_dev(cid, log_n, d_a.ptr, d_b.ptr, d_c.ptr, d_h.ptr, d_work.ptr, ok, None))
-        d_work.free()
-        d_c.free()
+        N.check(lib.zk_qap_h_dev(cid, log_n, ws["a"].ptr, ws["b"].ptr, ws["c"].ptr, ws["h"].ptr, ws["work"].ptr, ok, None))
         if not ok.value:
             raise ValueError("(U * V - W) did not divided by Z to zero")
-        return DeviceQapResult(n, d_a, d_b, d_h, d_w)
+        return DeviceQapResult(n, ws["a"], ws["b"], ws["h"], ws["w"])
 
     # ---- reference-shaped API ---------------------------------------------------------------------
     def evaluate_witness(self, witness: list):
