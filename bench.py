@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra", action="store_true", help="also time NTT 2^22 and report it under 'extra'")
+    ap.add_argument("--precompute", action="store_true", help="plan flag ZK_MSM_PRECOMPUTE (fixed-base table 2^(cw) P_i, shared buckets)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -88,7 +89,7 @@ def main():
     N.check(lib.zk_point_mul(cid, grp, N.u64p(gen), N.u64p(N.ints_to_limbs([dot])), N.u64p(expected)))
 
     handle = N._u64(0)
-    N.check(lib.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, 0, args.window_bits, handle))
+    N.check(lib.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, N.MSM_PRECOMPUTE if args.precompute else 0, args.window_bits, handle))
     c_bits, nwin = N._i(0), N._i(0)
     N.check(lib.zk_msm_plan_windows(handle, c_bits, nwin))
     ranges = window_ranges(nwin.value, world)
@@ -173,6 +174,7 @@ def main():
                 "log_n": args.log_n,
                 "window_bits": c_bits.value,
                 "windows": nwin.value,
+                "precompute": bool(args.precompute),
                 "parallelism": f"window-sharded x{world}" if world > 1 else "single GPU",
             },
             "roofline": {

@@ -100,6 +100,49 @@ def test_msm_window_sizes_and_sharding(gpu, c):
         N.check(gpu.zk_msm_plan_destroy(h))
 
 
+@pytest.mark.parametrize("name,cid,grp,c", [("BN254", 0, 1, 0), ("BN254", 0, 1, 9), ("BN254", 0, 2, 0), ("BLS12_381", 1, 1, 0), ("BLS12_381", 1, 2, 6)])
+def test_msm_precomputed_table(gpu, name, cid, grp, c):
+    """ZK_MSM_PRECOMPUTE: fixed-base table 2^(c w) P_i with one shared bucket set gives the same point,
+    also for window-range partials, truncated scalar vectors and the edge cases"""
+    from zksnake_amd.parallel import sum_points, window_ranges
+    cv = pyref.curve_by_name(name)
+    g = pyref.Group(cv, grp)
+    n = 700
+    _, bases = oracle_bases(cid, grp, n, 90 + grp)
+    pts = corc.limbs_to_points(bases, cid, grp)
+    vals, _ = rand_scalars(n, cv.r, 91)
+    vals[0], vals[1], vals[2] = 0, 1, cv.r - 1
+    pts[5] = pts[4]; pts[7] = g.neg(pts[6]); vals[7] = vals[6]; pts[8] = None
+    bases = corc.points_to_limbs(pts, cid, grp)
+    sc = N.ints_to_limbs(vals, 4)
+    exp = corc.msm(cid, grp, sc, bases, threads=8)
+    PW = N.point_limbs(cid, grp)
+    h = N._u64(0)
+    N.check(gpu.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, N.MSM_PRECOMPUTE, c, h))
+    try:
+        out = np.zeros(PW, dtype=np.uint64)
+        N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, 0, 0, N.u64p(out), None))
+        assert (out == exp).all()
+        cb, nw = N._i(0), N._i(0)
+        N.check(gpu.zk_msm_plan_windows(h, cb, nw))
+        parts = []
+        for first, count in window_ranges(nw.value, 3):
+            part = np.zeros(PW, dtype=np.uint64)
+            N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, first, count, N.u64p(part), None))
+            parts.append(part)
+        assert (sum_points(cid, grp, parts) == exp).all()
+        N.check(gpu.zk_msm_plan_run(h, 50, sc.ctypes.data, 0, 0, 0, N.u64p(out), None))
+        assert (out == corc.msm(cid, grp, sc[:50], bases[:50], threads=8)).all()
+        # asynchronous form on the plan's own stream
+        N.check(gpu.zk_msm_plan_enqueue(h, n, sc.ctypes.data, 0, 0, 0, N.STREAM_PLAN))
+        assert gpu.zk_msm_plan_enqueue(h, n, sc.ctypes.data, 0, 0, 0, N.STREAM_PLAN) == N.ZK_ERR_ARG  # one run in flight
+        N.check(gpu.zk_msm_plan_finish(h, N.u64p(out)))
+        assert (out == exp).all()
+        assert gpu.zk_msm_plan_finish(h, N.u64p(out)) == N.ZK_ERR_ARG
+    finally:
+        N.check(gpu.zk_msm_plan_destroy(h))
+
+
 @pytest.mark.parametrize("name,cid", CURVES)
 @pytest.mark.parametrize("grp", [1, 2])
 def test_batch_mul(gpu, name, cid, grp):

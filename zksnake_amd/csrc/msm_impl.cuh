@@ -261,7 +261,7 @@ static __global__ void scan_add_kernel(uint32_t* out, uint32_t n, const uint32_t
 
 static __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const uint16_t* __restrict__ dig, uint32_t n, int c,
                                                                int w_first, int nchunk, uint32_t chunk_len, int shared_buckets,
-                                                               const uint32_t* __restrict__ hist,
+                                                               uint32_t table_stride, const uint32_t* __restrict__ hist,
                                                                const uint32_t* __restrict__ bucket_start,
                                                                uint32_t* __restrict__ sorted) {
     extern __shared__ uint32_t lds[];
@@ -276,7 +276,7 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const uint
     if (hi > n) hi = n;
     const uint16_t* d = dig + (size_t)w * n;
     // with shared buckets the point reference addresses the precomputed table row (w, i)
-    const uint32_t ref_base = shared_buckets ? (uint32_t)w * n : 0;
+    const uint32_t ref_base = shared_buckets ? (uint32_t)w * table_stride : 0;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
         int v = (int)d[i] - (int)B;
         if (v != 0) {
@@ -475,6 +475,25 @@ __global__ void bases_to_mont_kernel(const uint32_t* __restrict__ in, uint64_t n
     store_affine<F>(out + i * AW, p);
 }
 
+// ZK_MSM_PRECOMPUTE: table[w][i] = 2^(c w) * P_i (affine, Montgomery) for w = 1 .. nwin-1; row 0 is the input.
+// With these rows every window adds into ONE shared bucket set: the bucket reduction and the host tail shrink
+// by the number of windows and the Horner pass disappears.  One lane per point, c doublings per row and one
+// inversion per row (a one-time cost per proving key: ~8k field products per point).
+template <class G>
+__global__ __launch_bounds__(256) void precompute_kernel(uint32_t* __restrict__ table, uint32_t n, int c, int nwin) {
+    typedef typename G::F F;
+    constexpr int AW = 2 * F::LIMBS;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> p = load_affine<F>(table + (size_t)i * AW);
+    for (int w = 1; w < nwin; ++w) {
+        XYZZ<F> acc = xyzz_dbl_affine<F>(p);
+        for (int k = 1; k < c; ++k) acc = xyzz_dbl<F>(acc);
+        p = xyzz_to_affine<F>(acc);
+        store_affine<F>(table + ((size_t)w * n + i) * AW, p);
+    }
+}
+
 // out[i] = k_i * P_i (affine, canonical).  broadcast: one base for all.
 template <class G>
 __global__ __launch_bounds__(128) void batch_mul_kernel(const uint32_t* __restrict__ scalars,
@@ -524,6 +543,7 @@ struct MsmPlan : MsmPlanBase {
     static constexpr int XW = 4 * F::LIMBS;
 
     uint64_t n = 0;
+    bool pre = false;  // ZK_MSM_PRECOMPUTE: shared bucket set over a table of 2^(c w) P_i
     uint32_t B = 0, R = 0, C = 0;
     int nchunk = 0;
     uint32_t chunk_len = 0, seg_len = 0, max_segs = 0;
@@ -549,7 +569,7 @@ struct MsmPlan : MsmPlanBase {
     }
 
     int init(uint64_t n_points, const void* bases, int bases_on_device, int flags, int window_bits) {
-        (void)flags;  // ZK_MSM_PRECOMPUTE: not built yet, the general path is used
+        pre = (flags & ZK_MSM_PRECOMPUTE) != 0;
         if (n_points == 0 || n_points > (1ull << 26)) return fail(ZK_ERR_ARG, "MSM size must be in [1, 2^26]");
         n = n_points;
         c = window_bits > 0 ? window_bits : pick_window_bits(n);
@@ -573,10 +593,10 @@ struct MsmPlan : MsmPlanBase {
         seg_len = (uint32_t)sl;
         uint64_t n_keys = (uint64_t)nwin * B;
         uint64_t ms = entries / seg_len + n_keys + 1;
-        if (ms > 0x7FFFFFFFull) return fail(ZK_ERR_ARG, "MSM too large");
+        if (ms > 0x7FFFFFFFull || entries > 0x7FFFFFFFull) return fail(ZK_ERR_ARG, "MSM too large");
         max_segs = (uint32_t)ms;
 
-        ZK_HIP(hipMalloc(&d_bases, n * AW * 4));
+        ZK_HIP(hipMalloc(&d_bases, (pre ? (uint64_t)nwin : 1ull) * n * AW * 4));
         if (bases_on_device) {
             hipLaunchKernelGGL(bases_to_mont_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0,
                                (const uint32_t*)bases, n, d_bases);
@@ -592,6 +612,10 @@ struct MsmPlan : MsmPlanBase {
             ZK_HIP(e);
         }
         ZK_HIP(hipGetLastError());
+        if (pre) {
+            hipLaunchKernelGGL(precompute_kernel<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_bases, (uint32_t)n, c, nwin);
+            ZK_HIP(hipGetLastError());
+        }
         ZK_HIP(hipMalloc(&d_scalars, n * FrP::W * 4));
         ZK_HIP(hipMalloc(&d_dig, (size_t)nwin * n * 2));
         ZK_HIP(hipMalloc(&d_hist, (size_t)nwin * nchunk * B * 4));
@@ -649,7 +673,8 @@ struct MsmPlan : MsmPlanBase {
                 ZK_HIP(hipMemcpyAsync(d_scalars, scalars, (size_t)m * FrP::W * 4, hipMemcpyHostToDevice, st));
                 sc = d_scalars;
             }
-            const uint32_t n_keys = (uint32_t)w_count * B;
+            const uint32_t groups = pre ? 1u : (uint32_t)w_count;  // bucket sets
+            const uint32_t n_keys = groups * B;
             const uint32_t ch_len = (m + nchunk - 1) / nchunk;
             ZK_HIP(hipEventRecord(ev[0], st));
             // 1. digits
@@ -663,14 +688,14 @@ struct MsmPlan : MsmPlanBase {
             // 2. histogram
             hipLaunchKernelGGL(hist_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), B * 4, st, d_dig, m, c, w_first, nchunk, ch_len, d_hist);
             // 3. prefix + scans
-            hipLaunchKernelGGL(prefix_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_hist, nchunk, B, n_keys, d_total);
+            hipLaunchKernelGGL(prefix_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_hist, pre ? w_count * nchunk : nchunk, B, n_keys, d_total);
             int rc;
             if ((rc = exclusive_scan(d_total, n_keys, d_bstart, st))) return rc;
             ZK_HIP(hipMemsetAsync(d_big_count, 0, 4, st));
             hipLaunchKernelGGL(runs_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_bstart, n_keys, seg_len, d_nseg, d_big_list, d_big_count);
             if ((rc = exclusive_scan(d_nseg, n_keys, d_sstart, st))) return rc;
             // 4. scatter
-            hipLaunchKernelGGL(scatter_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), B * 4, st, d_dig, m, c, w_first, nchunk, ch_len, 0, d_hist, d_bstart, d_sorted);
+            hipLaunchKernelGGL(scatter_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), B * 4, st, d_dig, m, c, w_first, nchunk, ch_len, pre ? 1 : 0, (uint32_t)n, d_hist, d_bstart, d_sorted);
             ZK_HIP(hipEventRecord(ev[1], st));
             // 5. accumulate
             uint64_t lanes = ((uint64_t)w_count * m + seg_len - 1) / seg_len;
@@ -680,15 +705,15 @@ struct MsmPlan : MsmPlanBase {
             hipLaunchKernelGGL(combine_kernel<G>, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_partials, d_sstart, n_keys, d_buckets);
             hipLaunchKernelGGL(combine_big_kernel<G>, dim3(256), dim3(BIG_THREADS), 0, st, d_partials, d_sstart, d_big_list, d_big_count, d_buckets);
             // 7. reduce: rows (sum over lo), cols (sum over hi), weighted sums
-            uint32_t n_rows = (uint32_t)w_count * R, n_cols = (uint32_t)w_count * C;
+            uint32_t n_rows = groups * R, n_cols = groups * C;
             SumJob rows = {n_rows, R, B, C, 1u, C, 0u};
             SumJob cols = {n_cols, C, B, 1u, C, R, n_rows};
             // d_rows holds the row sums followed by the column sums
             hipLaunchKernelGGL(strided_sum_kernel<G>, dim3(((n_rows + n_cols) * 64 + 255) / 256), dim3(256), 0, st, d_buckets, d_rows, rows, cols);
-            hipLaunchKernelGGL(weighted_sum_kernel<G>, dim3(2 * w_count), dim3(HS_THREADS), 0, st, d_rows, R, (uint32_t)w_count,
+            hipLaunchKernelGGL(weighted_sum_kernel<G>, dim3(2 * groups), dim3(HS_THREADS), 0, st, d_rows, R, groups,
                                d_rows + (size_t)n_rows * XW, C, d_final);
             ZK_HIP(hipGetLastError());
-            ZK_HIP(hipMemcpyAsync(h_final, d_final, (size_t)w_count * 4 * XW * 4, hipMemcpyDeviceToHost, st));
+            ZK_HIP(hipMemcpyAsync(h_final, d_final, (size_t)groups * 4 * XW * 4, hipMemcpyDeviceToHost, st));
             ZK_HIP(hipEventRecord(ev[3], st));
         }
         q_pending = true;
@@ -704,16 +729,18 @@ struct MsmPlan : MsmPlanBase {
         if (q_m > 0) {
             ZK_HIP(hipEventSynchronize(ev[3]));
             // 8. host tail: window sum W = C * S_R + S_C + T ; Horner over windows
-            for (int wl = w_count - 1; wl >= 0; --wl) {
+            const int groups = pre ? 1 : w_count;
+            for (int wl = groups - 1; wl >= 0; --wl) {
                 const uint32_t* rowp = h_final + (size_t)wl * 2 * XW;
-                const uint32_t* colp = h_final + ((size_t)w_count * 2 + (size_t)wl * 2) * XW;
+                const uint32_t* colp = h_final + ((size_t)groups * 2 + (size_t)wl * 2) * XW;
                 XYZZ<F> sr = load_xyzz_host<F>(rowp), tot = load_xyzz_host<F>(rowp + XW), scol = load_xyzz_host<F>(colp);
                 for (uint32_t k = 1; k < C; k <<= 1) sr = xyzz_dbl<F>(sr);
                 XYZZ<F> wsum = xyzz_add<F>(xyzz_add<F>(sr, scol), tot);
-                if (wl != w_count - 1) for (int k = 0; k < c; ++k) total = xyzz_dbl<F>(total);
+                if (wl != groups - 1) for (int k = 0; k < c; ++k) total = xyzz_dbl<F>(total);
                 total = xyzz_add<F>(total, wsum);
             }
-            for (int k = 0; k < c * w_first; ++k) total = xyzz_dbl<F>(total);
+            // the precomputed rows already carry the 2^(c w) weights
+            if (!pre) for (int k = 0; k < c * w_first; ++k) total = xyzz_dbl<F>(total);
             ZK_HIP(hipEventRecord(ev[4], q_stream));
             ZK_HIP(hipEventSynchronize(ev[4]));
             (void)hipEventElapsedTime(&timings[0], ev[0], ev[1]);
