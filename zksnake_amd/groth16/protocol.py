@@ -41,6 +41,7 @@ class Groth16:
         self.verifying_key = None
         self._toxic = None      # tests may pin (tau, alpha, beta, gamma, delta)
         self._blinding = None   # tests may pin (r, s)
+        self.precompute_keys = True  # proving-key MSM plans use the fixed-base table (ZK_MSM_PRECOMPUTE)
         self.last_timings = {}
 
     # ------------------------------------------------------------------------------------------
@@ -91,7 +92,7 @@ class Groth16:
         """start <bases[:count], scalars> (scalars already in HBM) on the plan's own stream"""
         lib = N.load()
         arr = _as_array(self.E, bases, group)
-        handle = arr.plan(slot)
+        handle = arr.plan(slot, precompute=self.precompute_keys)
         N.check(lib.zk_msm_plan_enqueue(handle, count, d_scalars, 1, 0, 0, N.STREAM_PLAN))
         return arr, handle
 
