@@ -43,7 +43,9 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extra", action="store_true", help="also time NTT 2^22 and report it under 'extra'")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary numbers reported under 'extra' (N = 1 only): "
+                    "fixed-base MSM, NTT 2^22, Groth16 prove 2^20")
+    ap.add_argument("--prove-log-n", type=int, default=20)
     ap.add_argument("--precompute", action="store_true", help="plan flag ZK_MSM_PRECOMPUTE (fixed-base table 2^(cw) P_i, shared buckets)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
@@ -213,8 +215,8 @@ def main():
                           f"window c={corc.ark_window(n)}, 1 thread (the default zksnake wheel runs ark's MSM single-threaded)",
                 "seconds": round(cpu_s, 3),
             }
-        if args.extra and world == 1:
-            line["extra"] = extra_metrics(lib, torch, dev)
+        if not args.no_extra and world == 1:
+            line["extra"] = extra_metrics(lib, torch, dev, args, bases, d_scalars, expected)
         print(json.dumps(line), flush=True)
 
     N.check(lib.zk_msm_plan_destroy(handle))
@@ -222,27 +224,75 @@ def main():
         dist.destroy_process_group()
 
 
-def extra_metrics(lib, torch, dev):
-    """secondary numbers (not the headline): BN254 Fr NTT at 2^22 resident in HBM."""
+def extra_metrics(lib, torch, dev, args, bases, d_scalars, expected):
+    """secondary numbers (not the headline), all checked for correctness before they are reported"""
     out = {}
+    stream = torch.cuda.current_stream().cuda_stream
+    cid, grp = N.CURVE_BN254, N.G1
+    n = bases.shape[0]
+
+    # (1) the same MSM with the fixed-base table (ZK_MSM_PRECOMPUTE): what Groth16.prove uses for proving keys
+    h = N._u64(0)
+    N.check(lib.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, N.MSM_PRECOMPUTE, args.window_bits, h))
+    res = np.zeros(bases.shape[1], dtype=np.uint64)
+    for _ in range(2):
+        N.check(lib.zk_msm_plan_run(h, n, d_scalars.data_ptr(), 1, 0, 0, N.u64p(res), stream))
+    assert (res == expected).all(), "fixed-base MSM differs from the closed form"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        N.check(lib.zk_msm_plan_run(h, n, d_scalars.data_ptr(), 1, 0, 0, N.u64p(res), stream))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    tm = (N.ctypes.c_float * 5)()
+    lib.zk_msm_plan_timings(h, tm, 5)
+    out["msm_fixed_base_table"] = {"ms": round(ms, 4), "Mscalar/s": round(n / ms / 1e3, 2), "accumulate_kernel_ms": round(tm[1], 4),
+                                   "note": "bases expanded once to 2^(c w) P_i rows (1 GiB at 2^20), one shared bucket set"}
+    N.check(lib.zk_msm_plan_destroy(h))
+
+    # (2) BN254 Fr NTT at 2^22, resident in HBM (BASELINE config 3)
     log_n = 22
-    n = 1 << log_n
-    limbs = W.splitmix64(W.SEED_NTT, 4 * n).reshape(n, 4)
+    m = 1 << log_n
+    limbs = W.splitmix64(W.SEED_NTT, 4 * m).reshape(m, 4)
     limbs[:, 3] &= np.uint64((1 << 60) - 1)
     d = torch.from_numpy(limbs.view(np.int64)).to(dev)
-    stream = torch.cuda.current_stream().cuda_stream
     N.check(lib.zk_ntt_dev(0, 0, log_n, d.data_ptr(), stream))
-    torch.cuda.synchronize()
+    N.check(lib.zk_ntt_dev(0, 1, log_n, d.data_ptr(), stream))
+    assert (d.cpu().numpy().view(np.uint64) == limbs).all(), "iNTT(NTT(x)) != x"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 10
     e0.record()
     for _ in range(reps):
         N.check(lib.zk_ntt_dev(0, 0, log_n, d.data_ptr(), stream))
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    out["ntt_bn254_fr_2^22"] = {"ms": round(ms, 4), "Melem/s": round(n / ms / 1e3, 2),
-                                "achieved_GB/s": round(64 * n / ms / 1e6, 2)}
+    out["ntt_bn254_fr_2^22"] = {"ms": round(ms, 4), "Melem/s": round(m / ms / 1e3, 2), "achieved_GB/s": round(64 * m / ms / 1e6, 2),
+                                "frac_of_8TB/s": round(64 * m / ms / 1e6 / HBM_PEAK_GBPS, 5)}
+    del d
+
+    # (3) Groth16 prove on the benchmark chain circuit (BASELINE config 4), witness as host limb arrays
+    from zksnake_amd.arithmetization import R1CS
+    from zksnake_amd.groth16 import Groth16
+    pn = 1 << args.prove_log_n
+    r = constant.BN254_SCALAR_FIELD
+    A, B, C, w, n_col = W.chain_circuit(pn, r)
+    g = Groth16(R1CS.from_triplets(A, B, C, pn, n_col, 2, "BN254"), "BN254")
+    g._toxic = tuple(W.field_stream(W.SEED_PROVE, 5, r)[1])
+    g._blinding = tuple(W.field_stream(W.SEED_PROVE, 2, r, offset=5)[1])
+    g.setup()
+    pub, prv = N.ints_to_limbs(w[:2]), N.ints_to_limbs(w[2:])
+    times = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        proof = g.prove(pub, prv)
+        times.append((time.perf_counter() - t0) * 1e3)
+    ok = g.verify(proof, w[:2])
+    out[f"groth16_prove_bn254_2^{args.prove_log_n}"] = {"ms": round(min(times[1:]), 3), "first_ms_incl_key_upload": round(times[0], 1),
+                                                       "verifies": bool(ok), "proof_sha256": __import__("hashlib").sha256(proof.to_bytes()).hexdigest()}
+    if not ok:
+        raise SystemExit("Groth16 proof does not verify")
     return out
 
 

@@ -147,3 +147,18 @@ def test_groth16_chain_2_12(gpu):
     proof = g.prove(N.ints_to_limbs(w[:2]), N.ints_to_limbs(w[2:]))
     trip = (list(zip(*A)), list(zip(*B)), list(zip(*C)), n, n_col, 2, w)
     assert proof.to_bytes() == _oracle_proof_bytes(trip, cv)
+
+
+def test_groth16_bls12_381_chain_2_10(gpu):
+    """BLS12-381 twin of the benchmark circuit (BASELINE config 5 shape, one GPU, reduced size)"""
+    curve, cv = "BLS12_381", pyref.BLS12_381
+    n = 1 << 10
+    A, B, C, w, n_col = W.chain_circuit(n, cv.r)
+    r1cs = R1CS.from_triplets(A, B, C, n, n_col, 2, curve)
+    g = Groth16(r1cs, curve)
+    g._toxic, g._blinding = TOXIC, BLIND
+    g.setup()
+    proof = g.prove(N.ints_to_limbs(w[:2]), N.ints_to_limbs(w[2:]))
+    trip = (list(zip(*A)), list(zip(*B)), list(zip(*C)), n, n_col, 2, w)
+    assert proof.to_bytes() == _oracle_proof_bytes(trip, cv)
+    assert len(proof.to_bytes()) == 192 and g.verify(proof, w[:2])

@@ -161,14 +161,14 @@ def test_batch_mul(gpu, name, cid, grp):
     assert (out2 == corc.batch_mul(cid, grp, sc, exp)).all()
 
 
-def _known_dl_case(gpu, n, scalars_limbs, scalar_ints):
-    cid, grp, r = 0, 1, pyref.BN254.r
+def _known_dl_case(gpu, n, scalars_limbs, scalar_ints, cid=0, grp=1):
+    r = (pyref.BN254 if cid == 0 else pyref.BLS12_381).r
     k_limbs, k_ints = W.field_stream(W.SEED_MSM_BASES, n, r)
     gen = generator_limbs(gpu, cid, grp)
-    bases = np.zeros((n, 8), dtype=np.uint64)
+    bases = np.zeros((n, N.point_limbs(cid, grp)), dtype=np.uint64)
     N.check(gpu.zk_batch_mul(cid, grp, n, N.u64p(k_limbs), N.u64p(gen), 1, N.u64p(bases)))
     dot = sum(a * b for a, b in zip(scalar_ints, k_ints)) % r
-    exp = np.zeros(8, dtype=np.uint64)
+    exp = np.zeros(N.point_limbs(cid, grp), dtype=np.uint64)
     N.check(gpu.zk_point_mul(cid, grp, N.u64p(gen), N.u64p(N.ints_to_limbs([dot])), N.u64p(exp)))
     assert (_msm(gpu, cid, grp, scalars_limbs, bases) == exp).all()
 
@@ -178,6 +178,15 @@ def test_msm_2_20_closed_form(gpu):
     n = 1 << 20
     sc_limbs, sc_ints = W.field_stream(W.SEED_MSM_SCALARS, n, pyref.BN254.r)
     _known_dl_case(gpu, n, sc_limbs, sc_ints)
+
+
+@pytest.mark.parametrize("cid,grp,log_n", [(0, 2, 16), (1, 1, 18), (1, 2, 15)])
+def test_msm_closed_form_other_groups(gpu, cid, grp, log_n):
+    """BN254 G2 and the BLS12-381 twins at sizes where the closed form is the only cheap oracle"""
+    n = 1 << log_n
+    r = (pyref.BN254 if cid == 0 else pyref.BLS12_381).r
+    sc_limbs, sc_ints = W.field_stream(W.SEED_MSM_SCALARS, n, r)
+    _known_dl_case(gpu, n, sc_limbs, sc_ints, cid, grp)
 
 
 def test_msm_skewed_scalars(gpu):

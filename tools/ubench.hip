@@ -1,11 +1,12 @@
-// tools/ubench.hip -- VALU issue-rate microbenchmark for gfx950 (design input for field.cuh).
-// Measures sustained per-CU throughput of the instructions a big-integer Montgomery product
-// can be built from, and of fp_mul itself, at 1/2/4/8 waves per SIMD.
-//   hipcc -O3 --offload-arch=gfx950 -o ubench tools/ubench.hip && ./ubench
+// tools/ubench.hip -- VALU issue-rate microbenchmark for gfx950 (design input for csrc/field.cuh).
+// Sustained per-SIMD cost of the instructions a big-integer Montgomery product can be built from, and of the
+// library's own field operations, at 1/2/4/8 waves per SIMD.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o build/ubench tools/ubench.hip && ./build/ubench
+// The first-round run that motivated the 29-bit limb design (32-bit-limb CIOS: ~1900 cycles per BN254 product)
+// is kept in profiles/r01_ubench_valu.log.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include <vector>
 #include "../zksnake_amd/csrc/field.cuh"
 
 using namespace zkmi;
@@ -30,20 +31,6 @@ __global__ void k_mad64(uint64_t* out, uint32_t a, uint32_t b) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-__global__ void k_mullo(uint64_t* out, uint32_t a, uint32_t b) {
-    uint32_t acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = a + i + threadIdx.x;
-    for (int it = 0; it < ITERS; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = acc[i] * (b + i);
-    }
-    uint32_t s = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s ^= acc[i];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-
 __global__ void k_mulhi(uint64_t* out, uint32_t a, uint32_t b) {
     uint32_t acc[8];
 #pragma unroll
@@ -58,21 +45,7 @@ __global__ void k_mulhi(uint64_t* out, uint32_t a, uint32_t b) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-__global__ void k_mad24(uint64_t* out, uint32_t a, uint32_t b) {
-    uint32_t acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = a + i + threadIdx.x;
-    for (int it = 0; it < ITERS; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __umul24(acc[i], b + i) + acc[i];
-    }
-    uint32_t s = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s ^= acc[i];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-
-__global__ void k_add32(uint64_t* out, uint32_t a, uint32_t b) {
+__global__ void k_addxor(uint64_t* out, uint32_t a, uint32_t b) {
     uint32_t acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = a + i + threadIdx.x;
@@ -81,21 +54,6 @@ __global__ void k_add32(uint64_t* out, uint32_t a, uint32_t b) {
         for (int i = 0; i < 8; ++i) acc[i] = (acc[i] + b) ^ (uint32_t)it;
     }
     uint32_t s = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s ^= acc[i];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-
-__global__ void k_add64(uint64_t* out, uint32_t a, uint32_t b) {
-    uint64_t acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = ((uint64_t)a << 32) + i + threadIdx.x;
-    uint64_t inc = ((uint64_t)b << 31) | 0xFFFFFFF1u;
-    for (int it = 0; it < ITERS; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = acc[i] + inc + (uint64_t)i;
-    }
-    uint64_t s = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s ^= acc[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -116,89 +74,17 @@ __global__ void k_dfma(uint64_t* out, uint32_t a, uint32_t b) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = (uint64_t)s;
 }
 
-template <class P>
-__global__ void k_fpmul(uint64_t* out, uint32_t a, uint32_t b) {
-    Fp<P> x = fp_one<P>(), y = fp_one<P>();
-    x.v[0] += a + threadIdx.x;
-    y.v[0] += b + 7 * threadIdx.x;
+// OP: 0 mul, 1 sqr, 2 add+sub, 3 mul2
+template <class P, int OP>
+__global__ void k_field(uint64_t* out, uint32_t a, uint32_t b) {
+    Fp<P> x = fp_one<P>(), y = fp_const<P>(P::R2);
+    x.v[0] = (x.v[0] + a + threadIdx.x) & LIMB_MASK;
+    y.v[0] = (y.v[0] + b + 7 * threadIdx.x) & LIMB_MASK;
     for (int it = 0; it < ITERS / 16; ++it) {
-        x = fp_mul<P>(x, y);
-        y = fp_mul<P>(y, x);
-    }
-    uint64_t s = 0;
-#pragma unroll
-    for (int i = 0; i < P::N; ++i) s += x.v[i] ^ y.v[i];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-
-// V2: products as separate lo/hi words, accumulated with explicit 32-bit carry chains
-template <class P>
-__device__ __forceinline__ Fp<P> mul_v2(const Fp<P>& a, const Fp<P>& b) {
-    constexpr int N = P::N;
-    uint32_t t[N + 2];
-#pragma unroll
-    for (int i = 0; i < N + 2; ++i) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        uint32_t lo[N], hi[N];
-#pragma unroll
-        for (int j = 0; j < N; ++j) { uint64_t p = (uint64_t)a.v[j] * b.v[i]; lo[j] = (uint32_t)p; hi[j] = (uint32_t)(p >> 32); }
-        uint32_t c = 0, co;
-#pragma unroll
-        for (int j = 0; j < N; ++j) { t[j] = __builtin_addc(t[j], lo[j], c, &co); c = co; }
-        t[N] = __builtin_addc(t[N], 0u, c, &co); c = co;
-        t[N + 1] += c;
-        c = 0;
-#pragma unroll
-        for (int j = 0; j < N; ++j) { t[j + 1] = __builtin_addc(t[j + 1], hi[j], c, &co); c = co; }
-        t[N + 1] += c;
-        uint32_t m = t[0] * P::INV;
-#pragma unroll
-        for (int j = 0; j < N; ++j) { uint64_t p = (uint64_t)m * P::MOD[j]; lo[j] = (uint32_t)p; hi[j] = (uint32_t)(p >> 32); }
-        c = 0;
-#pragma unroll
-        for (int j = 0; j < N; ++j) { t[j] = __builtin_addc(t[j], lo[j], c, &co); c = co; }
-        t[N] = __builtin_addc(t[N], 0u, c, &co); c = co;
-        t[N + 1] += c;
-        c = 0;
-#pragma unroll
-        for (int j = 0; j < N; ++j) { t[j + 1] = __builtin_addc(t[j + 1], hi[j], c, &co); c = co; }
-        t[N + 1] += c;
-#pragma unroll
-        for (int j = 0; j <= N; ++j) t[j] = t[j + 1];
-        t[N + 1] = 0;
-    }
-    Fp<P> out;
-#pragma unroll
-    for (int i = 0; i < N; ++i) out.v[i] = t[i];
-    fp_reduce_once<P>(out);
-    return out;
-}
-
-
-template <class P>
-__global__ void k_fpmul2(uint64_t* out, uint32_t a, uint32_t b) {
-    Fp<P> x = fp_one<P>(), y = fp_one<P>();
-    x.v[0] += a + threadIdx.x;
-    y.v[0] += b + 7 * threadIdx.x;
-    for (int it = 0; it < ITERS / 16; ++it) {
-        x = mul_v2<P>(x, y);
-        y = mul_v2<P>(y, x);
-    }
-    uint64_t s = 0;
-#pragma unroll
-    for (int i = 0; i < P::N; ++i) s += x.v[i] ^ y.v[i];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-
-template <class P>
-__global__ void k_fpadd(uint64_t* out, uint32_t a, uint32_t b) {
-    Fp<P> x = fp_one<P>(), y = fp_one<P>();
-    x.v[0] += a + threadIdx.x;
-    y.v[0] += b + 7 * threadIdx.x;
-    for (int it = 0; it < ITERS / 16; ++it) {
-        x = fp_add<P>(x, y);
-        y = fp_sub<P>(y, x);
+        if (OP == 0) { x = fp_mul<P>(x, y); y = fp_mul<P>(y, x); }
+        if (OP == 1) { x = fp_sqr<P>(y); y = fp_sqr<P>(x); }
+        if (OP == 2) { x = fp_add<P>(x, y); y = fp_sub<P>(y, x); }
+        if (OP == 3) { x = fp_mul2<P>(x, y, y, x); y = fp_mul2<P>(y, x, x, x); }
     }
     uint64_t s = 0;
 #pragma unroll
@@ -225,29 +111,26 @@ static void run(const char* name, K kernel, double ops_per_thread, uint64_t* d_o
         double t = ms * 1e-3 / reps;
         double total_ops = ops_per_thread * blocks * 256.0;
         double waves = blocks * 4.0;
-        // cycles per wave-instruction per SIMD at 2.4 GHz, if all 1024 SIMDs are busy
-        double cyc = t * 2.4e9 / (ops_per_thread * waves / 1024.0);
-        printf("%-12s waves/SIMD=%d  %8.3f ms  %9.2f Gop/s  ~%6.2f cyc/wave-op/SIMD\n", name, wps, t * 1e3, total_ops / t * 1e-9, cyc);
+        double cyc = t * 2.4e9 / (ops_per_thread * waves / 1024.0);  // nominal 2.4 GHz, all 1024 SIMDs busy
+        printf("%-16s waves/SIMD=%d  %8.3f ms  %9.2f Gop/s  ~%7.1f cyc/wave-op/SIMD\n", name, wps, t * 1e3, total_ops / t * 1e-9, cyc);
     }
 }
 
 int main() {
     uint64_t* d_out;
     CK(hipMalloc(&d_out, sizeof(uint64_t) * 256 * 8 * 256));
-    hipDeviceProp_t prop;
-    CK(hipGetDeviceProperties(&prop, 0));
-    printf("device: %s, CUs=%d, clock=%d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
     run("mad_u64_u32", k_mad64, 8.0 * ITERS, d_out);
-    run("mul_lo_u32", k_mullo, 8.0 * ITERS, d_out);
-    run("mul_hi_u32", k_mulhi, 8.0 * ITERS, d_out);
-    run("mad_u32_u24", k_mad24, 8.0 * ITERS, d_out);
-    run("add_u32(+xor)", k_add32, 8.0 * ITERS, d_out);
-    run("add_u64", k_add64, 8.0 * ITERS, d_out);
+    run("mul_hi_u32+add", k_mulhi, 8.0 * ITERS, d_out);
+    run("add+xor (2 ops)", k_addxor, 8.0 * ITERS, d_out);
     run("fma_f64", k_dfma, 8.0 * ITERS, d_out);
-    run("fpmul BnFq", k_fpmul<BnFqParams>, 2.0 * (ITERS / 16), d_out);
-    run("fpmul2 BnFq", k_fpmul2<BnFqParams>, 2.0 * (ITERS / 16), d_out);
-    run("fpmul2 BlsFq", k_fpmul2<BlsFqParams>, 2.0 * (ITERS / 16), d_out);
-    run("fpmul BlsFq", k_fpmul<BlsFqParams>, 2.0 * (ITERS / 16), d_out);
-    run("fpadd BnFq", k_fpadd<BnFqParams>, 2.0 * (ITERS / 16), d_out);
+    const double f = 2.0 * (ITERS / 16);
+    run("fp_mul BnFq", k_field<BnFqParams, 0>, f, d_out);
+    run("fp_sqr BnFq", k_field<BnFqParams, 1>, f, d_out);
+    run("fp_add|sub BnFq", k_field<BnFqParams, 2>, f, d_out);
+    run("fp_mul2 BnFq", k_field<BnFqParams, 3>, f, d_out);
+    run("fp_mul BlsFq", k_field<BlsFqParams, 0>, f, d_out);
+    run("fp_sqr BlsFq", k_field<BlsFqParams, 1>, f, d_out);
+    run("fp_add|sub BlsFq", k_field<BlsFqParams, 2>, f, d_out);
+    run("fp_mul2 BlsFq", k_field<BlsFqParams, 3>, f, d_out);
     return 0;
 }
