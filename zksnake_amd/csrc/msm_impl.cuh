@@ -392,28 +392,34 @@ struct SumJob {
 
 template <class G>
 __global__ __launch_bounds__(256) void strided_sum_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                          SumJob j0, SumJob j1) {
+                                                          SumJob j0, SumJob j1, uint32_t lpo) {
+    // lpo lanes per output (16 or 64): with many outputs (one bucket set per window) 16 lanes each do
+    // count/16 sequential additions and a 4-level tree, which wastes far fewer lanes than a 6-level tree;
+    // with few outputs (shared bucket set) the stage is latency-bound and 64 lanes give the shortest chain.
     typedef typename G::F F;
     constexpr int XW = 4 * F::LIMBS;
-    uint32_t o = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    uint32_t lane = threadIdx.x & 63;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t o = gid / lpo;
+    const uint32_t sub = gid % lpo;
     SumJob job = j0;
     if (o >= j0.n_out) {
         o -= j0.n_out;
         job = j1;
     }
-    if (o >= job.n_out) return;  // whole wave exits together
-    size_t base = (size_t)(o / job.per_group) * job.group_stride + (size_t)(o % job.per_group) * job.outer;
+    const bool live = o < job.n_out;  // dead groups still take part in the shuffles
+    size_t base = live ? (size_t)(o / job.per_group) * job.group_stride + (size_t)(o % job.per_group) * job.outer : 0;
     XYZZ<F> acc = xyzz_inf<F>();
-    for (uint32_t j = lane; j < job.count; j += 64) {
-        XYZZ<F> p = load_xyzz<F>(in + (base + (size_t)j * job.inner) * XW);
-        acc = xyzz_add<F>(acc, p);
+    if (live) {
+        for (uint32_t j = sub; j < job.count; j += lpo) {
+            XYZZ<F> p = load_xyzz<F>(in + (base + (size_t)j * job.inner) * XW);
+            acc = xyzz_add<F>(acc, p);
+        }
     }
-    for (int m = 32; m >= 1; m >>= 1) {
-        XYZZ<F> other = shfl_xor_xyzz<F>(acc, m);
+    for (uint32_t m = lpo >> 1; m >= 1; m >>= 1) {
+        XYZZ<F> other = shfl_xor_xyzz<F>(acc, (int)m);
         acc = xyzz_add<F>(acc, other);
     }
-    if (lane == 0) store_xyzz<F>(out + ((size_t)job.out_offset + o) * XW, acc);
+    if (live && sub == 0) store_xyzz<F>(out + ((size_t)job.out_offset + o) * XW, acc);
 }
 
 // one workgroup per array of m <= 256 points: S = sum_j j * X_j and T = sum_j X_j
@@ -709,7 +715,8 @@ struct MsmPlan : MsmPlanBase {
             SumJob rows = {n_rows, R, B, C, 1u, C, 0u};
             SumJob cols = {n_cols, C, B, 1u, C, R, n_rows};
             // d_rows holds the row sums followed by the column sums
-            hipLaunchKernelGGL(strided_sum_kernel<G>, dim3(((n_rows + n_cols) * 64 + 255) / 256), dim3(256), 0, st, d_buckets, d_rows, rows, cols);
+            const uint32_t lpo = (n_rows + n_cols) >= 2048 ? 16u : 64u;
+            hipLaunchKernelGGL(strided_sum_kernel<G>, dim3(((n_rows + n_cols) * lpo + 255) / 256), dim3(256), 0, st, d_buckets, d_rows, rows, cols, lpo);
             hipLaunchKernelGGL(weighted_sum_kernel<G>, dim3(2 * groups), dim3(HS_THREADS), 0, st, d_rows, R, groups,
                                d_rows + (size_t)n_rows * XW, C, d_final);
             ZK_HIP(hipGetLastError());
