@@ -191,6 +191,17 @@ def main():
                 "kernel_ms": round(float(stage[1]), 4),
                 "note": "254-bit modular arithmetic makes this kernel integer-VALU bound, not HBM bound; see DESIGN.md",
             },
+            # the resource that actually binds: 32-bit integer multiply-add issue.  Per mixed addition the kernel
+            # executes 8 products (2 N^2 + N = 171 v_mad_u64_u32 at N = 9 limbs) and 2 squarings (135); the
+            # peak is the measured chip-wide v_mad_u64_u32 rate (profiles/r01_ubench_valu.log: 26.4 T/s).
+            "roofline_valu": {
+                "kernel": "accumulate_kernel<Bn254G1>",
+                "bound": "int32 multiply-add issue (v_mad_u64_u32)",
+                "achieved": round(nwin.value * n * (8 * 171 + 2 * 135) / acc_s / 1e12, 3) if acc_s > 0 and world == 1 else None,
+                "peak": 26.4,
+                "unit": "Tmad/s",
+                "frac": round(nwin.value * n * (8 * 171 + 2 * 135) / acc_s / 1e12 / 26.4, 4) if acc_s > 0 and world == 1 else None,
+            },
             "stage_ms": {
                 "digits_sort": round(float(stage[0]), 4),
                 "accumulate": round(float(stage[1]), 4),

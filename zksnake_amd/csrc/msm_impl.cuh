@@ -201,16 +201,20 @@ static __global__ void prefix_kernel(uint32_t* __restrict__ hist, int group_size
 //   nruns = 1 + (last_entry / seg_len) - (first_entry / seg_len)   consecutive partial slots.
 // Buckets with more than COMBINE_SMALL_MAX runs (skewed scalars: e.g. the short top window, or many equal
 // scalars) are listed in big_list and reduced by a whole workgroup each instead of one lane.
-constexpr uint32_t COMBINE_SMALL_MAX = 16;
+constexpr uint32_t COMBINE_SMALL_MAX = 16;    // <= 16 runs: one lane adds them up
+constexpr uint32_t COMBINE_WAVE_MAX = 2048;   // <= 2048 runs: one wave per bucket; above: one workgroup
 static __global__ void runs_kernel(const uint32_t* __restrict__ bucket_start, uint32_t n_keys, uint32_t seg_len,
                                    uint32_t* __restrict__ nruns, uint32_t* __restrict__ big_list,
                                    uint32_t* __restrict__ big_count) {
+    // big_list is filled from the front with wave-tier buckets and from the back with workgroup-tier buckets;
+    // big_count[0] / big_count[1] are the two lengths
     uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= n_keys) return;
     uint32_t s0 = bucket_start[key], s1 = bucket_start[key + 1];
     uint32_t r = s1 > s0 ? 1 + (s1 - 1) / seg_len - s0 / seg_len : 0;
     nruns[key] = r;
-    if (r > COMBINE_SMALL_MAX) big_list[atomicAdd(big_count, 1u)] = key;
+    if (r > COMBINE_WAVE_MAX) big_list[n_keys - 1 - atomicAdd(big_count + 1, 1u)] = key;
+    else if (r > COMBINE_SMALL_MAX) big_list[atomicAdd(big_count, 1u)] = key;
 }
 
 // two-level exclusive scan: blocks of 1024
@@ -348,22 +352,48 @@ __global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict
     store_xyzz<F>(buckets + (size_t)key * XW, acc);
 }
 
-// one workgroup per listed bucket: lanes stride over its runs, then a log-depth tree through LDS
+// wave tier: one wave per listed bucket, lanes stride over its runs, 6-level shuffle tree
+template <class G>
+__global__ __launch_bounds__(256) void combine_wave_kernel(const uint32_t* __restrict__ partials,
+                                                           const uint32_t* __restrict__ run_start,
+                                                           const uint32_t* __restrict__ big_list,
+                                                           const uint32_t* __restrict__ big_count,
+                                                           uint32_t* __restrict__ buckets) {
+    typedef typename G::F F;
+    constexpr int XW = 4 * F::LIMBS;
+    const uint32_t count = big_count[0];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t b = wave; b < count; b += n_waves) {
+        const uint32_t key = big_list[b];
+        const uint32_t s0 = run_start[key], s1 = run_start[key + 1];
+        XYZZ<F> v = xyzz_inf<F>();
+        for (uint32_t s = s0 + lane; s < s1; s += 64) v = xyzz_add<F>(v, load_xyzz<F>(partials + (size_t)s * XW));
+        for (int m = 32; m >= 1; m >>= 1) {
+            XYZZ<F> other = shfl_xor_xyzz<F>(v, m);
+            v = xyzz_add<F>(v, other);
+        }
+        if (lane == 0) store_xyzz<F>(buckets + (size_t)key * XW, v);
+    }
+}
+
+// workgroup tier: lanes stride over the runs, then a log-depth tree through LDS
 constexpr int BIG_THREADS = 256;
 template <class G>
 __global__ __launch_bounds__(BIG_THREADS) void combine_big_kernel(const uint32_t* __restrict__ partials,
                                                                   const uint32_t* __restrict__ run_start,
-                                                                  const uint32_t* __restrict__ big_list,
+                                                                  const uint32_t* __restrict__ big_list, uint32_t n_keys,
                                                                   const uint32_t* __restrict__ big_count,
                                                                   uint32_t* __restrict__ buckets) {
     typedef typename G::F F;
     constexpr int XW = 4 * F::LIMBS;
     constexpr int RW = XyzzRegs<F>::COUNT;
     __shared__ uint32_t sh[BIG_THREADS * RW];
-    const uint32_t count = *big_count;
+    const uint32_t count = big_count[1];
     const uint32_t j = threadIdx.x;
     for (uint32_t b = blockIdx.x; b < count; b += gridDim.x) {
-        const uint32_t key = big_list[b];
+        const uint32_t key = big_list[n_keys - 1 - b];
         const uint32_t s0 = run_start[key], s1 = run_start[key + 1];
         XYZZ<F> v = xyzz_inf<F>();
         for (uint32_t s = s0 + j; s < s1; s += BIG_THREADS) v = xyzz_add<F>(v, load_xyzz<F>(partials + (size_t)s * XW));
@@ -534,10 +564,11 @@ __global__ __launch_bounds__(128) void batch_mul_kernel(const uint32_t* __restri
 
 static int pick_window_bits(uint64_t n) {
     // bucket sets must fit the LDS histogram (c <= 16) and stay well filled
+    // measured on MI355X (BN254 G1): 2^14 -> 12, 2^16..2^20 -> 16; the tail is latency-bound, so fewer
+    // windows win as soon as the buckets are reasonably filled
     int lg = log2_u64(n < 2 ? 2 : n);
-    int c = lg - 4;
+    int c = lg >= 16 ? 16 : lg - 2;
     if (c < 4) c = 4;
-    if (c > 16) c = 16;
     return c;
 }
 
@@ -632,7 +663,7 @@ struct MsmPlan : MsmPlanBase {
         ZK_HIP(hipMalloc(&d_bsums, ((n_keys + SCAN_BLOCK - 1) / SCAN_BLOCK + 1) * 4));
         ZK_HIP(hipMalloc(&d_grand, 4));
         ZK_HIP(hipMalloc(&d_big_list, n_keys * 4));
-        ZK_HIP(hipMalloc(&d_big_count, 4));
+        ZK_HIP(hipMalloc(&d_big_count, 8));
         ZK_HIP(hipMalloc(&d_sorted, entries * 4));
         ZK_HIP(hipMalloc(&d_partials, (size_t)max_segs * XW * 4));
         ZK_HIP(hipMalloc(&d_buckets, n_keys * XW * 4));
@@ -697,7 +728,7 @@ struct MsmPlan : MsmPlanBase {
             hipLaunchKernelGGL(prefix_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_hist, pre ? w_count * nchunk : nchunk, B, n_keys, d_total);
             int rc;
             if ((rc = exclusive_scan(d_total, n_keys, d_bstart, st))) return rc;
-            ZK_HIP(hipMemsetAsync(d_big_count, 0, 4, st));
+            ZK_HIP(hipMemsetAsync(d_big_count, 0, 8, st));
             hipLaunchKernelGGL(runs_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_bstart, n_keys, seg_len, d_nseg, d_big_list, d_big_count);
             if ((rc = exclusive_scan(d_nseg, n_keys, d_sstart, st))) return rc;
             // 4. scatter
@@ -709,7 +740,8 @@ struct MsmPlan : MsmPlanBase {
             ZK_HIP(hipEventRecord(ev[2], st));
             // 6. combine
             hipLaunchKernelGGL(combine_kernel<G>, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_partials, d_sstart, n_keys, d_buckets);
-            hipLaunchKernelGGL(combine_big_kernel<G>, dim3(256), dim3(BIG_THREADS), 0, st, d_partials, d_sstart, d_big_list, d_big_count, d_buckets);
+            hipLaunchKernelGGL(combine_wave_kernel<G>, dim3(512), dim3(256), 0, st, d_partials, d_sstart, d_big_list, d_big_count, d_buckets);
+            hipLaunchKernelGGL(combine_big_kernel<G>, dim3(256), dim3(BIG_THREADS), 0, st, d_partials, d_sstart, d_big_list, n_keys, d_big_count, d_buckets);
             // 7. reduce: rows (sum over lo), cols (sum over hi), weighted sums
             uint32_t n_rows = groups * R, n_cols = groups * C;
             SumJob rows = {n_rows, R, B, C, 1u, C, 0u};
