@@ -162,3 +162,19 @@ def test_groth16_bls12_381_chain_2_10(gpu):
     trip = (list(zip(*A)), list(zip(*B)), list(zip(*C)), n, n_col, 2, w)
     assert proof.to_bytes() == _oracle_proof_bytes(trip, cv)
     assert len(proof.to_bytes()) == 192 and g.verify(proof, w[:2])
+
+
+def test_groth16_from_circom_poseidon(gpu):
+    """the reference's circom fixture end to end (tests/test_groth16.py:92-115): load tests/stub/test_poseidon.r1cs,
+    derive the witness from main.a, main.b, main.c = 1, 2, 3, prove, verify, reject a forged public output"""
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "test_poseidon.r1cs")
+    r1cs = R1CS.from_file(path)
+    w = r1cs.solve_wires({2: 1, 3: 2, 4: 3})
+    pub, priv = w[:r1cs.n_public], w[r1cs.n_public:]
+    assert r1cs.is_sat(pub, priv)
+    g = Groth16(r1cs)
+    g.setup()
+    proof = g.prove(pub, priv)
+    assert g.verify(proof, pub)
+    assert not g.verify(proof, [pub[0], (pub[1] + 1) % r1cs.p])

@@ -80,6 +80,65 @@ class R1CS:
                 w.append(v % self.p)
         return w[: self.n_public], w[self.n_public:]
 
+    def solve_wires(self, known: dict) -> list:
+        """Witness by constraint propagation for matrix-only systems (circom files): starting from the wires in
+        `known` ({wire index: value}; wire 0 = 1 is implied), repeatedly take a constraint <A,w>*<B,w> = <C,w> in
+        which exactly one wire is unknown and appears linearly, and solve for it.  This is the job the reference's
+        symbolic solver does for file circuits (src/arithmetization/symbolic.rs:652-806, one-unknown isolation)."""
+        assert self.A is not None, "R1CS is not compiled"
+        p = self.p
+        n_col = self.A.n_col
+        w = [None] * n_col
+        w[0] = 1
+        for k, v in known.items():
+            w[int(k)] = int(v) % p
+        rows = {}
+        for name, m in (("a", self.A), ("b", self.B), ("c", self.C)):
+            for r, c, v in m.triplets:
+                rows.setdefault(r, {"a": [], "b": [], "c": []})[name].append((c, v % p))
+
+        def split(terms):
+            acc, unk = 0, []
+            for c, v in terms:
+                if w[c] is None:
+                    unk.append((c, v))
+                else:
+                    acc = (acc + v * w[c]) % p
+            return acc, unk
+
+        pending = list(rows.values())
+        progress = True
+        while pending and progress:
+            progress = False
+            rest = []
+            for row in pending:
+                (sa, ua), (sb, ub), (sc, uc) = split(row["a"]), split(row["b"]), split(row["c"])
+                n_unknown = len({c for c, _ in ua + ub + uc})
+                if n_unknown == 0:
+                    continue
+                solved = False
+                if n_unknown == 1:
+                    if uc and not ua and not ub and len(uc) == 1:
+                        c, v = uc[0]
+                        w[c] = (sa * sb - sc) * pow(v, -1, p) % p
+                        solved = True
+                    elif ua and not ub and not uc and len(ua) == 1 and sb % p:
+                        c, v = ua[0]
+                        w[c] = (sc * pow(sb, -1, p) - sa) * pow(v, -1, p) % p
+                        solved = True
+                    elif ub and not ua and not uc and len(ub) == 1 and sa % p:
+                        c, v = ub[0]
+                        w[c] = (sc * pow(sa, -1, p) - sb) * pow(v, -1, p) % p
+                        solved = True
+                if solved:
+                    progress = True
+                else:
+                    rest.append(row)
+            pending = rest
+        if any(x is None for x in w):
+            raise ValueError("constraint propagation could not determine every wire from the given inputs")
+        return w
+
     def is_sat(self, public_witness: list, private_witness: list):
         assert self.A is not None, "R1CS is not compiled"
         w = list(public_witness) + list(private_witness)
