@@ -684,31 +684,48 @@ struct MsmPlan : MsmPlanBase {
     typedef typename G::Fr FrP;
     static constexpr int AW = 2 * F::LIMBS;
     static constexpr int XW = 4 * F::LIMBS;
+    static constexpr int MAX_LANES = 4;
+
+    // A run can be split over `n_lanes` groups of windows ("lanes"), each with its own stream and workspace
+    // (meant to let one group's latency-bound reduction run beside the next group's accumulation; see init()
+    // for why the default is one lane).
+    struct Lane {
+        uint32_t *hist = nullptr, *total = nullptr, *nseg = nullptr, *bstart = nullptr, *sstart = nullptr;
+        uint32_t *bsums = nullptr, *grand = nullptr, *big_list = nullptr, *big_count = nullptr;
+        uint32_t *sorted = nullptr, *partials = nullptr, *buckets = nullptr, *rows = nullptr, *fin = nullptr;
+        hipStream_t stream = nullptr;
+        hipEvent_t ev_begin = nullptr, ev_acc0 = nullptr, ev_acc1 = nullptr, ev_done = nullptr;
+        int w_first = 0, w_count = 0;  // windows of the run in flight
+        uint32_t groups = 0;           // bucket sets of the run in flight
+        size_t h_offset = 0;           // words into h_final
+    };
 
     uint64_t n = 0;
     bool pre = false;  // ZK_MSM_PRECOMPUTE: shared bucket set over a table of 2^(c w) P_i
     uint32_t B = 0, R = 0, C = 0;
     int nchunk = 0;
     int range_log = 0;  // general mode: log2(buckets per sort workgroup)
-    uint32_t chunk_len = 0, seg_len = 0, max_segs = 0;
-    // device buffers
+    uint32_t seg_len = 0;
+    int n_lanes = 1, lane_windows = 0;
+    Lane lanes[MAX_LANES];
+    // shared device buffers
     uint32_t* d_bases = nullptr;
     uint32_t* d_scalars = nullptr;
     uint16_t* d_dig = nullptr;
-    uint32_t *d_hist = nullptr, *d_total = nullptr, *d_nseg = nullptr, *d_bstart = nullptr, *d_sstart = nullptr;
-    uint32_t *d_bsums = nullptr, *d_grand = nullptr, *d_big_list = nullptr, *d_big_count = nullptr;
-    uint32_t *d_sorted = nullptr, *d_partials = nullptr, *d_buckets = nullptr, *d_rows = nullptr, *d_cols = nullptr,
-             *d_final = nullptr;
-    uint32_t* h_final = nullptr;  // pinned
-    hipEvent_t ev[5];
-    bool have_events = false;
+    uint32_t* h_final = nullptr;  // pinned: per bucket set (S_R, T, S_C, -)
+    hipEvent_t ev_start = nullptr, ev_digits = nullptr, ev_end = nullptr;
 
     ~MsmPlan() override {
-        void* bufs[] = {d_bases, d_scalars, d_dig, d_hist, d_total, d_nseg, d_bstart, d_sstart, d_bsums, d_grand, d_big_list, d_big_count,
-                        d_sorted, d_partials, d_buckets, d_rows, d_cols, d_final};
-        for (void* b : bufs) if (b) (void)hipFree(b);
+        for (Lane& l : lanes) {
+            void* bufs[] = {l.hist, l.total, l.nseg, l.bstart, l.sstart, l.bsums, l.grand, l.big_list, l.big_count,
+                            l.sorted, l.partials, l.buckets, l.rows, l.fin};
+            for (void* p : bufs) if (p) (void)hipFree(p);
+            if (l.stream) (void)hipStreamDestroy(l.stream);
+            for (hipEvent_t e : {l.ev_begin, l.ev_acc0, l.ev_acc1, l.ev_done}) if (e) (void)hipEventDestroy(e);
+        }
+        for (void* p : {(void*)d_bases, (void*)d_scalars, (void*)d_dig}) if (p) (void)hipFree(p);
         if (h_final) (void)hipHostFree(h_final);
-        if (have_events) for (auto& e : ev) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ev_start, ev_digits, ev_end}) if (e) (void)hipEventDestroy(e);
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
 
@@ -725,10 +742,9 @@ struct MsmPlan : MsmPlanBase {
         R = 1u << rl;
         C = B / R;
         if (C > 256) return fail(ZK_ERR_ARG, "window too wide for the reduction stage");
-        // chunks: enough workgroups to fill the chip, at most 65535 entries per LDS counter is no issue (u32)
+        // chunks: enough workgroups to fill the chip
         nchunk = (int)std::max<uint64_t>(1, std::min<uint64_t>(256 / (uint64_t)std::max(1, nwin) + 1, (n + 4095) / 4096));
-        chunk_len = (uint32_t)((n + nchunk - 1) / nchunk);
-        // bucket ranges: about 256..512 sort workgroups in total, at least 64 buckets each
+        // bucket ranges (general mode, small inputs): about 256 sort workgroups in total, at least 64 buckets each
         {
             uint32_t wgs = 256u;
             if (const char* e = getenv("ZKMI_SORT_WGS")) wgs = (uint32_t)atoi(e);  // tuning knob
@@ -745,10 +761,16 @@ struct MsmPlan : MsmPlanBase {
         if (sl < 8) sl = 8;
         if (sl > 64) sl = 64;
         seg_len = (uint32_t)sl;
-        uint64_t n_keys = (uint64_t)nwin * B;
-        uint64_t ms = entries / seg_len + n_keys + 1;
-        if (ms > 0x7FFFFFFFull || entries > 0x7FFFFFFFull) return fail(ZK_ERR_ARG, "MSM too large");
-        max_segs = (uint32_t)ms;
+        if (entries > 0x7FFFFFFFull) return fail(ZK_ERR_ARG, "MSM too large");
+        // measured at 2^20 (BN254 G1): 1 / 2 / 4 lanes -> 2.47 / 2.59 / 3.36 ms.  A full-occupancy accumulation kernel
+        // leaves no wave slots for another stream's reduction kernels, so the hoped-for overlap does not happen;
+        // the default is a single lane and the knob stays for experiments.
+        n_lanes = 1;
+        if (const char* e = getenv("ZKMI_LANES")) n_lanes = atoi(e);
+        if (n_lanes < 1) n_lanes = 1;
+        if (n_lanes > MAX_LANES) n_lanes = MAX_LANES;
+        if (n_lanes > nwin) n_lanes = nwin;
+        lane_windows = (nwin + n_lanes - 1) / n_lanes;
 
         ZK_HIP(hipMalloc(&d_bases, (pre ? (uint64_t)nwin : 1ull) * n * AW * 4));
         if (bases_on_device) {
@@ -772,24 +794,33 @@ struct MsmPlan : MsmPlanBase {
         }
         ZK_HIP(hipMalloc(&d_scalars, n * FrP::W * 4));
         ZK_HIP(hipMalloc(&d_dig, (size_t)nwin * (n + 8) * 2));
-        ZK_HIP(hipMalloc(&d_hist, (size_t)nwin * nchunk * B * 4));
-        ZK_HIP(hipMalloc(&d_total, n_keys * 4));
-        ZK_HIP(hipMalloc(&d_nseg, n_keys * 4));
-        ZK_HIP(hipMalloc(&d_bstart, (n_keys + 1) * 4));
-        ZK_HIP(hipMalloc(&d_sstart, (n_keys + 1) * 4));
-        ZK_HIP(hipMalloc(&d_bsums, ((n_keys + SCAN_BLOCK - 1) / SCAN_BLOCK + 1) * 4));
-        ZK_HIP(hipMalloc(&d_grand, 4));
-        ZK_HIP(hipMalloc(&d_big_list, n_keys * 4));
-        ZK_HIP(hipMalloc(&d_big_count, 8));
-        ZK_HIP(hipMalloc(&d_sorted, entries * 4));
-        ZK_HIP(hipMalloc(&d_partials, (size_t)max_segs * XW * 4));
-        ZK_HIP(hipMalloc(&d_buckets, n_keys * XW * 4));
-        ZK_HIP(hipMalloc(&d_rows, (size_t)nwin * (R + C) * XW * 4));
-        ZK_HIP(hipMalloc(&d_final, (size_t)nwin * 4 * XW * 4));
         ZK_HIP(hipHostMalloc(&h_final, (size_t)nwin * 4 * XW * 4));
-        for (auto& e : ev) ZK_HIP(hipEventCreate(&e));
-        have_events = true;
+        for (hipEvent_t* e : {&ev_start, &ev_digits, &ev_end}) ZK_HIP(hipEventCreate(e));
         ZK_HIP(hipStreamCreate(&own_stream));
+        // per-lane workspaces: lane 0 can hold every window (single-lane runs), the others lane_windows windows
+        for (int i = 0; i < n_lanes; ++i) {
+            Lane& l = lanes[i];
+            const uint64_t lw = i == 0 ? (uint64_t)nwin : (uint64_t)lane_windows;
+            const uint64_t keys = (pre ? 1ull : lw) * B;
+            const uint64_t lane_entries = lw * n;
+            const uint64_t max_segs = lane_entries / seg_len + keys + 2;
+            ZK_HIP(hipMalloc(&l.hist, lw * nchunk * B * 4));
+            ZK_HIP(hipMalloc(&l.total, keys * 4));
+            ZK_HIP(hipMalloc(&l.nseg, keys * 4));
+            ZK_HIP(hipMalloc(&l.bstart, (keys + 1) * 4));
+            ZK_HIP(hipMalloc(&l.sstart, (keys + 1) * 4));
+            ZK_HIP(hipMalloc(&l.bsums, ((keys + SCAN_BLOCK - 1) / SCAN_BLOCK + 1) * 4));
+            ZK_HIP(hipMalloc(&l.grand, 4));
+            ZK_HIP(hipMalloc(&l.big_list, keys * 4));
+            ZK_HIP(hipMalloc(&l.big_count, 8));
+            ZK_HIP(hipMalloc(&l.sorted, lane_entries * 4));
+            ZK_HIP(hipMalloc(&l.partials, max_segs * XW * 4));
+            ZK_HIP(hipMalloc(&l.buckets, keys * XW * 4));
+            ZK_HIP(hipMalloc(&l.rows, lw * (R + C) * XW * 4));
+            ZK_HIP(hipMalloc(&l.fin, lw * 4 * XW * 4));
+            ZK_HIP(hipStreamCreate(&l.stream));
+            for (hipEvent_t* e : {&l.ev_begin, &l.ev_acc0, &l.ev_acc1, &l.ev_done}) ZK_HIP(hipEventCreate(e));
+        }
         // LDS above 64 KiB needs the opt-in
         int lds_bytes = (int)(B * 4);
         ZK_HIP(hipFuncSetAttribute((const void*)hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
@@ -800,17 +831,70 @@ struct MsmPlan : MsmPlanBase {
         return ZK_OK;
     }
 
-    int exclusive_scan(const uint32_t* in, uint32_t cnt, uint32_t* out, hipStream_t st) {
+    int exclusive_scan(Lane& l, const uint32_t* in, uint32_t cnt, uint32_t* out, hipStream_t st) {
         uint32_t blocks = (cnt + SCAN_BLOCK - 1) / SCAN_BLOCK;
-        hipLaunchKernelGGL(scan_block_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, st, in, cnt, out, d_bsums);
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, d_bsums, blocks, d_grand);
-        hipLaunchKernelGGL(scan_add_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, st, out, cnt, d_bsums, d_grand);
+        hipLaunchKernelGGL(scan_block_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, st, in, cnt, out, l.bsums);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, l.bsums, blocks, l.grand);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, st, out, cnt, l.bsums, l.grand);
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
 
+    // stages 2..7 + D2H for the windows [w_first, w_first + w_count) on stream st
+    int run_lane(Lane& l, uint32_t m, uint32_t dstride, hipStream_t st, hipEvent_t after_acc) {
+        const int w_first = l.w_first, w_count = l.w_count;
+        const uint32_t groups = l.groups;
+        const uint32_t n_keys = groups * B;
+        const uint32_t ch_len = (m + nchunk - 1) / nchunk;
+        int rc;
+        ZK_HIP(hipEventRecord(l.ev_begin, st));
+        // general mode, small inputs: bucket-range partition (measured faster up to 2^18); otherwise the
+        // chunked counting sort with the XCD-aware scatter
+        const bool ranged = !pre && m < (1u << 19);
+        if (ranged) {
+            hipLaunchKernelGGL(hist_range_kernel, dim3(w_count * (B >> range_log)), dim3(SORT_THREADS), (4u << range_log), st, d_dig, m, dstride, c, w_first, range_log, l.total);
+        } else {
+            hipLaunchKernelGGL(hist_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), B * 4, st, d_dig, m, dstride, c, w_first, nchunk, ch_len, l.hist);
+            hipLaunchKernelGGL(prefix_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, l.hist, pre ? w_count * nchunk : nchunk, B, n_keys, l.total);
+        }
+        if ((rc = exclusive_scan(l, l.total, n_keys, l.bstart, st))) return rc;
+        ZK_HIP(hipMemsetAsync(l.big_count, 0, 8, st));
+        hipLaunchKernelGGL(runs_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, l.bstart, n_keys, seg_len, l.nseg, l.big_list, l.big_count);
+        if ((rc = exclusive_scan(l, l.nseg, n_keys, l.sstart, st))) return rc;
+        if (ranged) {
+            hipLaunchKernelGGL(scatter_range_kernel, dim3(w_count * (B >> range_log)), dim3(SORT_THREADS), (4u << range_log), st, d_dig, m, dstride, c, w_first, range_log, l.bstart, l.sorted);
+        } else {
+            const unsigned blocks = pre ? (unsigned)(w_count * nchunk) : (unsigned)(8 * ((w_count + 7) / 8) * nchunk);
+            hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(SORT_THREADS), B * 4, st, d_dig, m, dstride, c, w_first, w_count, nchunk, ch_len, pre ? 1 : 0, (uint32_t)n, l.hist, l.bstart, l.sorted);
+        }
+        // lanes are staggered: this lane's accumulation starts when the previous lane's has finished, so that the
+        // previous lane's low-occupancy reduction runs beside it (two accumulations side by side gain nothing)
+        if (after_acc) ZK_HIP(hipStreamWaitEvent(st, after_acc, 0));
+        ZK_HIP(hipEventRecord(l.ev_acc0, st));
+        // 5. accumulate
+        uint64_t lanes_needed = ((uint64_t)w_count * m + seg_len - 1) / seg_len;
+        hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((lanes_needed + 255) / 256)), dim3(256), 0, st, d_bases, l.sorted, l.bstart, l.sstart, n_keys, seg_len, l.partials);
+        ZK_HIP(hipEventRecord(l.ev_acc1, st));
+        // 6. combine
+        hipLaunchKernelGGL(combine_kernel<G>, dim3((n_keys + 255) / 256), dim3(256), 0, st, l.partials, l.sstart, n_keys, l.buckets);
+        hipLaunchKernelGGL(combine_wave_kernel<G>, dim3(512), dim3(256), 0, st, l.partials, l.sstart, l.big_list, l.big_count, l.buckets);
+        hipLaunchKernelGGL(combine_big_kernel<G>, dim3(256), dim3(BIG_THREADS), 0, st, l.partials, l.sstart, l.big_list, n_keys, l.big_count, l.buckets);
+        // 7. reduce: rows (sum over lo), cols (sum over hi), weighted sums
+        uint32_t n_rows = groups * R, n_cols = groups * C;
+        SumJob rows = {n_rows, R, B, C, 1u, C, 0u};
+        SumJob cols = {n_cols, C, B, 1u, C, R, n_rows};
+        const uint32_t lpo = (n_rows + n_cols) >= 2048 ? 32u : 64u;  // measured: 8/16/32/64 -> 0.52/0.46/0.44/0.56 ms
+        hipLaunchKernelGGL(strided_sum_kernel<G>, dim3(((n_rows + n_cols) * lpo + 255) / 256), dim3(256), 0, st, l.buckets, l.rows, rows, cols, lpo);
+        hipLaunchKernelGGL(weighted_sum_kernel<G>, dim3(2 * groups), dim3(HS_THREADS), 0, st, l.rows, R, groups,
+                           l.rows + (size_t)n_rows * XW, C, l.fin);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipMemcpyAsync(h_final + l.h_offset, l.fin, (size_t)groups * 4 * XW * 4, hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipEventRecord(l.ev_done, st));
+        return ZK_OK;
+    }
+
     // state carried from enqueue() to finish()
-    int q_first = 0, q_count = 0;
+    int q_first = 0, q_count = 0, q_lanes = 0;
     uint32_t q_m = 0;
     hipStream_t q_stream = nullptr;
     bool q_pending = false;
@@ -822,19 +906,16 @@ struct MsmPlan : MsmPlanBase {
         if (w_count <= 0) { w_first = 0; w_count = nwin; }
         if (w_first < 0 || w_first + w_count > nwin) return fail(ZK_ERR_ARG, "window range out of bounds");
         const uint32_t m = (uint32_t)n_scalars;
-        q_first = w_first; q_count = w_count; q_m = m; q_stream = st;
+        q_first = w_first; q_count = w_count; q_m = m; q_stream = st; q_lanes = 0;
         if (m > 0) {
             const uint32_t* sc = (const uint32_t*)scalars;
             if (!on_device) {
                 ZK_HIP(hipMemcpyAsync(d_scalars, scalars, (size_t)m * FrP::W * 4, hipMemcpyHostToDevice, st));
                 sc = d_scalars;
             }
-            const uint32_t groups = pre ? 1u : (uint32_t)w_count;  // bucket sets
-            const uint32_t n_keys = groups * B;
-            const uint32_t ch_len = (m + nchunk - 1) / nchunk;
             const uint32_t dstride = (m + 7u) & ~7u;
-            ZK_HIP(hipEventRecord(ev[0], st));
-            // 1. digits
+            ZK_HIP(hipEventRecord(ev_start, st));
+            // 1. digits (all windows, once)
             DigitBias bias;
             memset(&bias, 0, sizeof(bias));
             for (int w = 0; w < nwin; ++w) {
@@ -842,48 +923,30 @@ struct MsmPlan : MsmPlanBase {
                 bias.v[bit >> 5] |= 1u << (bit & 31);
             }
             hipLaunchKernelGGL(digits_kernel<FrP>, dim3((m + 255) / 256), dim3(256), 0, st, sc, m, dstride, c, nwin, bias, d_dig);
-            int rc;
-            // general mode, small inputs: bucket-range partition (measured faster up to 2^18); otherwise the
-            // chunked counting sort with the XCD-aware scatter
-            const bool ranged = !pre && m < (1u << 19);
-            if (ranged) {
-                hipLaunchKernelGGL(hist_range_kernel, dim3(w_count * (B >> range_log)), dim3(SORT_THREADS), (4u << range_log), st, d_dig, m, dstride, c, w_first, range_log, d_total);
-            } else {
-                hipLaunchKernelGGL(hist_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), B * 4, st, d_dig, m, dstride, c, w_first, nchunk, ch_len, d_hist);
-                hipLaunchKernelGGL(prefix_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_hist, pre ? w_count * nchunk : nchunk, B, n_keys, d_total);
+            ZK_HIP(hipEventRecord(ev_digits, st));
+            // split the requested windows over the lanes (big problems only: small ones are latency-bound anyway)
+            int use = ((uint64_t)w_count * m >= (1ull << 22) && w_count >= 4) ? n_lanes : 1;
+            if (use > w_count) use = w_count;
+            q_lanes = use;
+            int first = w_first;
+            size_t h_off = 0;
+            for (int i = 0; i < use; ++i) {
+                Lane& l = lanes[i];
+                int cnt = w_count / use + (i < w_count % use ? 1 : 0);
+                l.w_first = first;
+                l.w_count = cnt;
+                l.groups = pre ? 1u : (uint32_t)cnt;
+                l.h_offset = h_off;
+                first += cnt;
+                h_off += (size_t)l.groups * 4 * XW;
+                hipStream_t ls = use == 1 ? st : l.stream;
+                if (use > 1) ZK_HIP(hipStreamWaitEvent(ls, ev_digits, 0));
+                int rc = run_lane(l, m, dstride, ls, i > 0 ? lanes[i - 1].ev_acc1 : nullptr);
+                if (rc) return rc;
             }
-            if ((rc = exclusive_scan(d_total, n_keys, d_bstart, st))) return rc;
-            ZK_HIP(hipMemsetAsync(d_big_count, 0, 8, st));
-            hipLaunchKernelGGL(runs_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_bstart, n_keys, seg_len, d_nseg, d_big_list, d_big_count);
-            if ((rc = exclusive_scan(d_nseg, n_keys, d_sstart, st))) return rc;
-            // 4. scatter
-            if (ranged) {
-                hipLaunchKernelGGL(scatter_range_kernel, dim3(w_count * (B >> range_log)), dim3(SORT_THREADS), (4u << range_log), st, d_dig, m, dstride, c, w_first, range_log, d_bstart, d_sorted);
-            } else {
-                const unsigned blocks = pre ? (unsigned)(w_count * nchunk) : (unsigned)(8 * ((w_count + 7) / 8) * nchunk);
-                hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(SORT_THREADS), B * 4, st, d_dig, m, dstride, c, w_first, w_count, nchunk, ch_len, pre ? 1 : 0, (uint32_t)n, d_hist, d_bstart, d_sorted);
-            }
-            ZK_HIP(hipEventRecord(ev[1], st));
-            // 5. accumulate
-            uint64_t lanes = ((uint64_t)w_count * m + seg_len - 1) / seg_len;
-            hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, d_bases, d_sorted, d_bstart, d_sstart, n_keys, seg_len, d_partials);
-            ZK_HIP(hipEventRecord(ev[2], st));
-            // 6. combine
-            hipLaunchKernelGGL(combine_kernel<G>, dim3((n_keys + 255) / 256), dim3(256), 0, st, d_partials, d_sstart, n_keys, d_buckets);
-            hipLaunchKernelGGL(combine_wave_kernel<G>, dim3(512), dim3(256), 0, st, d_partials, d_sstart, d_big_list, d_big_count, d_buckets);
-            hipLaunchKernelGGL(combine_big_kernel<G>, dim3(256), dim3(BIG_THREADS), 0, st, d_partials, d_sstart, d_big_list, n_keys, d_big_count, d_buckets);
-            // 7. reduce: rows (sum over lo), cols (sum over hi), weighted sums
-            uint32_t n_rows = groups * R, n_cols = groups * C;
-            SumJob rows = {n_rows, R, B, C, 1u, C, 0u};
-            SumJob cols = {n_cols, C, B, 1u, C, R, n_rows};
-            // d_rows holds the row sums followed by the column sums
-            const uint32_t lpo = (n_rows + n_cols) >= 2048 ? 32u : 64u;  // measured: 8/16/32/64 -> 0.52/0.46/0.44/0.56 ms
-            hipLaunchKernelGGL(strided_sum_kernel<G>, dim3(((n_rows + n_cols) * lpo + 255) / 256), dim3(256), 0, st, d_buckets, d_rows, rows, cols, lpo);
-            hipLaunchKernelGGL(weighted_sum_kernel<G>, dim3(2 * groups), dim3(HS_THREADS), 0, st, d_rows, R, groups,
-                               d_rows + (size_t)n_rows * XW, C, d_final);
-            ZK_HIP(hipGetLastError());
-            ZK_HIP(hipMemcpyAsync(h_final, d_final, (size_t)groups * 4 * XW * 4, hipMemcpyDeviceToHost, st));
-            ZK_HIP(hipEventRecord(ev[3], st));
+            // later work on the caller's stream is ordered after every lane
+            if (use > 1) for (int i = 0; i < use; ++i) ZK_HIP(hipStreamWaitEvent(st, lanes[i].ev_done, 0));
+            ZK_HIP(hipEventRecord(ev_end, st));
         }
         q_pending = true;
         return ZK_OK;
@@ -893,30 +956,42 @@ struct MsmPlan : MsmPlanBase {
         std::lock_guard<std::mutex> lock(mu);
         if (!q_pending) return fail(ZK_ERR_ARG, "zk_msm_plan_finish without a pending run");
         q_pending = false;
-        const int w_first = q_first, w_count = q_count;
         XYZZ<F> total = xyzz_inf<F>();
         if (q_m > 0) {
-            ZK_HIP(hipEventSynchronize(ev[3]));
-            // 8. host tail: window sum W = C * S_R + S_C + T ; Horner over windows
-            const int groups = pre ? 1 : w_count;
-            for (int wl = groups - 1; wl >= 0; --wl) {
-                const uint32_t* rowp = h_final + (size_t)wl * 2 * XW;
-                const uint32_t* colp = h_final + ((size_t)groups * 2 + (size_t)wl * 2) * XW;
-                XYZZ<F> sr = load_xyzz_host<F>(rowp), tot = load_xyzz_host<F>(rowp + XW), scol = load_xyzz_host<F>(colp);
-                for (uint32_t k = 1; k < C; k <<= 1) sr = xyzz_dbl<F>(sr);
-                XYZZ<F> wsum = xyzz_add<F>(xyzz_add<F>(sr, scol), tot);
-                if (wl != groups - 1) for (int k = 0; k < c; ++k) total = xyzz_dbl<F>(total);
-                total = xyzz_add<F>(total, wsum);
+            ZK_HIP(hipEventSynchronize(ev_end));
+            // 8. host tail: per bucket set W = C * S_R + S_C + T ; Horner over windows (highest first)
+            bool first_set = true;
+            for (int li = q_lanes - 1; li >= 0; --li) {
+                const Lane& l = lanes[li];
+                const int groups = (int)l.groups;
+                for (int wl = groups - 1; wl >= 0; --wl) {
+                    const uint32_t* rowp = h_final + l.h_offset + (size_t)wl * 2 * XW;
+                    const uint32_t* colp = h_final + l.h_offset + ((size_t)groups * 2 + (size_t)wl * 2) * XW;
+                    XYZZ<F> sr = load_xyzz_host<F>(rowp), tot = load_xyzz_host<F>(rowp + XW), scol = load_xyzz_host<F>(colp);
+                    for (uint32_t k = 1; k < C; k <<= 1) sr = xyzz_dbl<F>(sr);
+                    XYZZ<F> wsum = xyzz_add<F>(xyzz_add<F>(sr, scol), tot);
+                    // general mode: consecutive windows differ by 2^c; the precomputed rows already carry the weights
+                    if (!pre && !first_set) for (int k = 0; k < c; ++k) total = xyzz_dbl<F>(total);
+                    total = xyzz_add<F>(total, wsum);
+                    first_set = false;
+                }
             }
-            // the precomputed rows already carry the 2^(c w) weights
-            if (!pre) for (int k = 0; k < c * w_first; ++k) total = xyzz_dbl<F>(total);
-            ZK_HIP(hipEventRecord(ev[4], q_stream));
-            ZK_HIP(hipEventSynchronize(ev[4]));
-            (void)hipEventElapsedTime(&timings[0], ev[0], ev[1]);
-            (void)hipEventElapsedTime(&timings[1], ev[1], ev[2]);
-            (void)hipEventElapsedTime(&timings[2], ev[2], ev[3]);
-            (void)hipEventElapsedTime(&timings[3], ev[3], ev[4]);
-            (void)hipEventElapsedTime(&timings[4], ev[0], ev[4]);
+            if (!pre) for (int k = 0; k < c * q_first; ++k) total = xyzz_dbl<F>(total);
+            float sort_ms = 0, acc_ms = 0, red_ms = 0, t = 0;
+            for (int li = 0; li < q_lanes; ++li) {
+                const Lane& l = lanes[li];
+                if (hipEventElapsedTime(&t, l.ev_begin, l.ev_acc0) == hipSuccess) sort_ms += t;
+                if (hipEventElapsedTime(&t, l.ev_acc0, l.ev_acc1) == hipSuccess) acc_ms += t;
+                if (hipEventElapsedTime(&t, l.ev_acc1, l.ev_done) == hipSuccess) red_ms += t;
+            }
+            if (hipEventElapsedTime(&t, ev_start, ev_digits) == hipSuccess) sort_ms += t;
+            timings[0] = sort_ms;   // digits + sort, summed over lanes
+            timings[1] = acc_ms;    // accumulate kernel launches, summed over lanes
+            timings[2] = red_ms;    // combine + reduction + D2H, summed over lanes (lanes overlap each other)
+            ZK_HIP(hipEventRecord(ev_digits, q_stream));  // reuse as "host tail done" marker
+            ZK_HIP(hipEventSynchronize(ev_digits));
+            (void)hipEventElapsedTime(&timings[3], ev_end, ev_digits);
+            (void)hipEventElapsedTime(&timings[4], ev_start, ev_digits);
         }
         Affine<F> a = xyzz_to_affine<F>(total);
         uint32_t w[AW];
