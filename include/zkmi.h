@@ -140,8 +140,8 @@ int zk_msm_plan_enqueue(uint64_t handle, uint64_t n_scalars, const void* scalars
 int zk_msm_plan_finish(uint64_t handle, uint64_t* out);
 int zk_msm_plan_windows(uint64_t handle, int* window_bits, int* n_windows);
 /* milliseconds of the stages of the last zk_msm_plan_run on this plan, measured with HIP events on
- * the launch stream: [0] digits+sort, [1] bucket accumulation (dominant kernel), [2] bucket reduction,
- * [3] host tail, [4] total.  Returns the number of floats written. */
+ * the launch stream(s): [0] digits+sort, [1] bucket accumulation (dominant kernel; summed over its launches),
+ * [2] bucket combination + reduction + D2H, [3] host tail, [4] total.  Returns the number of floats written. */
 int zk_msm_plan_timings(uint64_t handle, float* ms, int cap);
 
 /* ---- single-point host arithmetic (PointG1 / PointG2 methods, src/bn254/curve.rs:25-324) -- */
