@@ -118,7 +118,7 @@ class Groth16:
         if isinstance(public_witness, np.ndarray) or isinstance(private_witness, np.ndarray):
             pub = public_witness if isinstance(public_witness, np.ndarray) else N.ints_to_limbs(public_witness, 4, q)
             prv = private_witness if isinstance(private_witness, np.ndarray) else N.ints_to_limbs(private_witness, 4, q)
-            witness = np.concatenate([pub.reshape(-1, 4), prv.reshape(-1, 4)], axis=0)
+            witness = (pub, prv)
         else:
             witness = list(public_witness) + list(private_witness)
         try:

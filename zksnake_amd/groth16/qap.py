@@ -81,11 +81,22 @@ class QAP:
         if n < 2:
             raise ValueError("the QAP needs at least 2 rows")
         log_n = n.bit_length() - 1
-        w_limbs = witness if isinstance(witness, np.ndarray) else N.ints_to_limbs(witness, 4, self.p)
-        if w_limbs.shape[0] != self.a.n_col:
+        # the witness may come as ints, as one limb array, or as (public, private) limb arrays (uploaded piecewise:
+        # concatenating 2^20 x 32 B on the host would cost more than the upload itself)
+        if isinstance(witness, tuple):
+            parts = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in witness]
+        elif isinstance(witness, np.ndarray):
+            parts = [witness]
+        else:
+            parts = [N.ints_to_limbs(witness, 4, self.p)]
+        if sum(p.shape[0] for p in parts) != self.a.n_col:
             raise ValueError("witness length does not match the number of R1CS columns")
         ws = self._workspace(n, self.a.n_col)
-        ws["w"].upload(w_limbs)
+        off = 0
+        for part in parts:
+            if part.shape[0]:
+                ws["w"].upload(part, offset=off)
+            off += part.nbytes
         for (rp, cl, vl), dst in zip(self._device_matrices(), (ws["a"], ws["b"], ws["c"])):
             N.check(lib.zk_spmv_dev(cid, n, rp.ptr, cl.ptr, vl.ptr, ws["w"].ptr, dst.ptr, None))
         ok = N._i(0)
