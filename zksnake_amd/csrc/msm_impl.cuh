@@ -760,6 +760,13 @@ struct MsmPlan : MsmPlanBase {
         uint64_t sl = (entries + target - 1) / target;
         if (sl < 8) sl = 8;
         if (sl > 64) sl = 64;
+        if (pre) {
+            // shared bucket set: keep a bucket within ~12 runs so that one lane can combine it
+            uint64_t per_bucket = entries / B;
+            uint64_t want = (per_bucket + 11) / 12;
+            if (want > sl) sl = want;
+            if (sl > 1024) sl = 1024;
+        }
         seg_len = (uint32_t)sl;
         if (entries > 0x7FFFFFFFull) return fail(ZK_ERR_ARG, "MSM too large");
         // measured at 2^20 (BN254 G1): 1 / 2 / 4 lanes -> 2.47 / 2.59 / 3.36 ms.  A full-occupancy accumulation kernel
