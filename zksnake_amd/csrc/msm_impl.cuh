@@ -742,8 +742,10 @@ struct MsmPlan : MsmPlanBase {
         R = 1u << rl;
         C = B / R;
         if (C > 256) return fail(ZK_ERR_ARG, "window too wide for the reduction stage");
-        // chunks: enough workgroups to fill the chip
-        nchunk = (int)std::max<uint64_t>(1, std::min<uint64_t>(256 / (uint64_t)std::max(1, nwin) + 1, (n + 4095) / 4096));
+        // chunked sort: windows x chunks workgroups of 1024 threads, ONE per CU (the LDS histogram takes 128 KiB at
+        // c = 16), so their number is kept at or just below the 256 CUs: 272 workgroups would run as 256 + 16,
+        // i.e. take twice as long.  nchunk is the value for a full-window run; window-range runs recompute it.
+        nchunk = chunks_for(nwin, n);
         // bucket ranges (general mode, small inputs): about 256 sort workgroups in total, at least 64 buckets each
         {
             uint32_t wgs = 256u;
@@ -811,7 +813,7 @@ struct MsmPlan : MsmPlanBase {
             const uint64_t keys = (pre ? 1ull : lw) * B;
             const uint64_t lane_entries = lw * n;
             const uint64_t max_segs = lane_entries / seg_len + keys + 2;
-            ZK_HIP(hipMalloc(&l.hist, lw * nchunk * B * 4));
+            ZK_HIP(hipMalloc(&l.hist, (size_t)std::max<uint64_t>(256, lw) * B * 4));  // windows x chunks <= max(256, windows)
             ZK_HIP(hipMalloc(&l.total, keys * 4));
             ZK_HIP(hipMalloc(&l.nseg, keys * 4));
             ZK_HIP(hipMalloc(&l.bstart, (keys + 1) * 4));
@@ -838,6 +840,14 @@ struct MsmPlan : MsmPlanBase {
         return ZK_OK;
     }
 
+    static int chunks_for(int windows, uint64_t count) {
+        int k = 256 / std::max(1, windows);
+        if (k < 1) k = 1;
+        uint64_t cap = (count + 4095) / 4096;  // at least 4096 entries per chunk
+        if ((uint64_t)k > cap) k = (int)std::max<uint64_t>(1, cap);
+        return k;
+    }
+
     int exclusive_scan(Lane& l, const uint32_t* in, uint32_t cnt, uint32_t* out, hipStream_t st) {
         uint32_t blocks = (cnt + SCAN_BLOCK - 1) / SCAN_BLOCK;
         hipLaunchKernelGGL(scan_block_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, st, in, cnt, out, l.bsums);
@@ -852,6 +862,7 @@ struct MsmPlan : MsmPlanBase {
         const int w_first = l.w_first, w_count = l.w_count;
         const uint32_t groups = l.groups;
         const uint32_t n_keys = groups * B;
+        const int nchunk = chunks_for(w_count, m);  // shadows the plan-wide value: this run's windows fill the chip
         const uint32_t ch_len = (m + nchunk - 1) / nchunk;
         int rc;
         ZK_HIP(hipEventRecord(l.ev_begin, st));
