@@ -148,6 +148,8 @@ int zk_msm_plan_timings(uint64_t handle, float* ms, int cap);
 
 int zk_point_add(int curve, int group, const uint64_t* a, const uint64_t* b, uint64_t* out);      /* __add__ */
 int zk_point_neg(int curve, int group, const uint64_t* a, uint64_t* out);                          /* __neg__ */
+/* sum of n affine points with one final inversion (the cross-rank combination of MSM partials) */
+int zk_point_sum(int curve, int group, uint64_t n, const uint64_t* points, uint64_t* out);
 int zk_point_mul(int curve, int group, const uint64_t* a, const uint64_t* scalar, uint64_t* out);  /* __mul__ */
 int zk_point_on_curve(int curve, int group, const uint64_t* a);                                    /* 1 / 0 */
 int zk_point_generator(int curve, int group, uint64_t* out);                                       /* g1() / g2() */

@@ -70,6 +70,7 @@ SIGNATURES = {
     "zk_msm_plan_timings": (_i, [_u64, ctypes.POINTER(ctypes.c_float), _i]),
     "zk_point_add": (_i, [_i, _i, _u64p, _u64p, _u64p]),
     "zk_point_neg": (_i, [_i, _i, _u64p, _u64p]),
+    "zk_point_sum": (_i, [_i, _i, _u64, _u64p, _u64p]),
     "zk_point_mul": (_i, [_i, _i, _u64p, _u64p, _u64p]),
     "zk_point_on_curve": (_i, [_i, _i, _u64p]),
     "zk_point_generator": (_i, [_i, _i, _u64p]),

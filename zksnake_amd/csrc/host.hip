@@ -351,6 +351,20 @@ int zk_point_add(int curve, int group, const uint64_t* a, const uint64_t* b, uin
 #undef CALL
 }
 
+int zk_point_sum(int curve, int group, uint64_t n, const uint64_t* points, uint64_t* out) {
+#define CALL(G)                                                              \
+    {                                                                        \
+        typedef G::F F;                                                      \
+        const size_t stride = F::LIMBS;  /* 64-bit limbs per affine point */    \
+        XYZZ<F> acc = xyzz_inf<F>();                                         \
+        for (uint64_t i = 0; i < n; ++i) xyzz_add_affine<F>(acc, load_point<G>(points + i * stride)); \
+        store_point<G>(out, xyzz_to_affine<F>(acc));                         \
+        return ZK_OK;                                                        \
+    }
+    ZK_DISPATCH_GROUP(curve, group, CALL);
+#undef CALL
+}
+
 int zk_point_neg(int curve, int group, const uint64_t* a, uint64_t* out) {
 #define CALL(G)                                                              \
     {                                                                        \

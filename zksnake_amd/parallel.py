@@ -23,15 +23,12 @@ def window_ranges(n_windows, world):
 
 
 def sum_points(curve_id, group, partials):
-    """host sum of affine points given as uint64 limb arrays"""
+    """host sum of affine points given as uint64 limb arrays (one inversion in total)"""
     lib = N.load()
-    acc = np.zeros(N.point_limbs(curve_id, group), dtype=np.uint64)
-    for part in partials:
-        part = np.ascontiguousarray(part, dtype=np.uint64)
-        nxt = np.zeros_like(acc)
-        N.check(lib.zk_point_add(curve_id, group, N.u64p(acc), N.u64p(part), N.u64p(nxt)))
-        acc = nxt
-    return acc
+    stack = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.uint64) for p in partials]))
+    out = np.zeros(N.point_limbs(curve_id, group), dtype=np.uint64)
+    N.check(lib.zk_point_sum(curve_id, group, stack.shape[0], N.u64p(stack), N.u64p(out)))
+    return out
 
 
 def all_gather_sum(curve_id, group, partial, device=None):
@@ -44,6 +41,11 @@ def all_gather_sum(curve_id, group, partial, device=None):
     mine = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).view(np.int64))
     if device is not None:
         mine = mine.to(device)
-    bucket = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(bucket, mine)
-    return sum_points(curve_id, group, [t.cpu().numpy().view(np.uint64) for t in bucket])
+    gathered = torch.zeros((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+    try:
+        dist.all_gather_into_tensor(gathered, mine)  # one flat collective (RCCL all-gather)
+    except (RuntimeError, NotImplementedError):
+        bucket = list(gathered.unbind(0))
+        dist.all_gather(bucket, mine)
+        gathered = torch.stack(bucket)
+    return sum_points(curve_id, group, list(gathered.cpu().numpy().view(np.uint64)))
