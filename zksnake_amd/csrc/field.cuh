@@ -139,6 +139,22 @@ ZK_HD Fp<P> fp_sub(const Fp<P>& a, const Fp<P>& b) {
     return s;
 }
 
+// a - b + 4p with NO carry propagation and no range selection: limbs stay below 2^31, the value below 6p.
+// Only valid as ONE operand of fp_mul (the other one normalized): 9 partial products of 2^31 * 2^29 plus the
+// reduction terms still fit the 64-bit column accumulators (used by the NTT butterflies, N = 9).  The constant is
+// 4p written with "borrow-proof" limbs (every limb but the top one borrows 2^29 from the limb above), so no limb
+// goes negative for any b < 2p.
+template <class P>
+ZK_HD Fp<P> fp_sub_lazy(const Fp<P>& a, const Fp<P>& b) {
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        uint32_t c = P::P4[i] + (i < P::N - 1 ? (1u << LIMB_BITS) : 0u) - (i > 0 ? 1u : 0u);
+        r.v[i] = a.v[i] + c - b.v[i];
+    }
+    return r;
+}
+
 template <class P>
 ZK_HD Fp<P> fp_neg(const Fp<P>& a) {
     return fp_sub<P>(fp_zero<P>(), a);

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(uint32_t* __restr
             for (int l = 0; l < N; ++l) { x.v[l] = lds[l][e0]; y.v[l] = lds[l][e1]; }
             Fp<P> w = load_fr<P>(tw + (size_t)k * W);
             Fp<P> sum = fp_add<P>(x, y);
-            Fp<P> dif = fp_mul<P>(fp_sub<P>(x, y), w);
+            Fp<P> dif = fp_mul<P>(w, fp_sub_lazy<P>(x, y));  // (x - y + 2p) un-normalized: fine as a product operand
 #pragma unroll
             for (int l = 0; l < N; ++l) { lds[l][e0] = sum.v[l]; lds[l][e1] = dif.v[l]; }
         }
