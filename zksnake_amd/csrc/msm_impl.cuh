@@ -977,8 +977,14 @@ struct MsmPlan : MsmPlanBase {
         XYZZ<F> total = xyzz_inf<F>();
         if (q_m > 0) {
             ZK_HIP(hipEventSynchronize(ev_end));
-            // 8. host tail: per bucket set W = C * S_R + S_C + T ; Horner over windows (highest first)
+            // 8. host tail.  Per bucket set W = C * S_R + S_C + T (C = 2^lc).
+            //    general mode: total = sum_w 2^(c w) W_w by Horner from the top window down; the factor C rides along:
+            //        t <- 2^lc * (2^(c - lc) * t + S_R) + S_C + T  =  2^c t + W      (c doublings per window, not c + lc)
+            //    fixed-base mode: the sets are plain summands:  total = C * (sum S_R) + sum (S_C + T)
+            int lc = 0;
+            while ((1u << lc) < C) ++lc;
             bool first_set = true;
+            XYZZ<F> rest = xyzz_inf<F>();
             for (int li = q_lanes - 1; li >= 0; --li) {
                 const Lane& l = lanes[li];
                 const int groups = (int)l.groups;
@@ -986,15 +992,24 @@ struct MsmPlan : MsmPlanBase {
                     const uint32_t* rowp = h_final + l.h_offset + (size_t)wl * 2 * XW;
                     const uint32_t* colp = h_final + l.h_offset + ((size_t)groups * 2 + (size_t)wl * 2) * XW;
                     XYZZ<F> sr = load_xyzz_host<F>(rowp), tot = load_xyzz_host<F>(rowp + XW), scol = load_xyzz_host<F>(colp);
-                    for (uint32_t k = 1; k < C; k <<= 1) sr = xyzz_dbl<F>(sr);
-                    XYZZ<F> wsum = xyzz_add<F>(xyzz_add<F>(sr, scol), tot);
-                    // general mode: consecutive windows differ by 2^c; the precomputed rows already carry the weights
-                    if (!pre && !first_set) for (int k = 0; k < c; ++k) total = xyzz_dbl<F>(total);
-                    total = xyzz_add<F>(total, wsum);
+                    if (pre) {
+                        total = xyzz_add<F>(total, sr);
+                        rest = xyzz_add<F>(rest, xyzz_add<F>(scol, tot));
+                    } else {
+                        if (!first_set) for (int k = 0; k < c - lc; ++k) total = xyzz_dbl<F>(total);
+                        total = xyzz_add<F>(total, sr);
+                        for (int k = 0; k < lc; ++k) total = xyzz_dbl<F>(total);
+                        total = xyzz_add<F>(total, xyzz_add<F>(scol, tot));
+                    }
                     first_set = false;
                 }
             }
-            if (!pre) for (int k = 0; k < c * q_first; ++k) total = xyzz_dbl<F>(total);
+            if (pre) {
+                for (int k = 0; k < lc; ++k) total = xyzz_dbl<F>(total);
+                total = xyzz_add<F>(total, rest);
+            } else {
+                for (int k = 0; k < c * q_first; ++k) total = xyzz_dbl<F>(total);
+            }
             float sort_ms = 0, acc_ms = 0, red_ms = 0, t = 0;
             for (int li = 0; li < q_lanes; ++li) {
                 const Lane& l = lanes[li];
