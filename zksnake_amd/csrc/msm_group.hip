@@ -1,15 +1,34 @@
 // msm_group.hip -- instantiates the MSM kernels and plan for ONE curve group (ZK_GROUP = Bn254G1, ...).
-// Compiled four times by the Makefile; field multiplications are inlined here (29-bit limb products are
-// ~230 instructions), which is why the instantiations are kept in separate translation units.
+// Compiled by the Makefile once per group and per part, so that the heavy kernels (field products inlined:
+// a BLS12-381 G2 mixed addition is ~14k instructions) build in parallel:
+//   ZK_PART 0: the plan (host code) and the small kernels; the heavy kernels are only declared (extern template)
+//   ZK_PART 1: accumulate / precompute / batch_mul / bases_to_mont kernels
+//   ZK_PART 2: combine (3 tiers) / strided_sum / weighted_sum kernels
 #include "msm_impl.cuh"
 
 #ifndef ZK_GROUP
-#error "compile with -DZK_GROUP=<Bn254G1|Bn254G2|Bls381G1|Bls381G2>"
+#error "compile with -DZK_GROUP=<Bn254G1|Bn254G2|Bls381G1|Bls381G2> -DZK_PART=<0|1|2>"
+#endif
+#ifndef ZK_PART
+#define ZK_PART 0
 #endif
 #define ZK_CAT2(a, b) a##b
 #define ZK_CAT(a, b) ZK_CAT2(a, b)
 
 namespace zkmi {
+
+#if ZK_PART == 1
+template __global__ void accumulate_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*);
+template __global__ void precompute_kernel<ZK_GROUP>(uint32_t*, uint32_t, int, int);
+template __global__ void batch_mul_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, int, uint64_t, uint32_t*);
+template __global__ void bases_to_mont_kernel<ZK_GROUP>(const uint32_t*, uint64_t, uint32_t*);
+#elif ZK_PART == 2
+template __global__ void combine_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, uint32_t, uint32_t*);
+template __global__ void combine_wave_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*);
+template __global__ void combine_big_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const uint32_t*, uint32_t*);
+template __global__ void strided_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t*, SumJob, SumJob, uint32_t);
+template __global__ void weighted_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t, uint32_t, const uint32_t*, uint32_t, uint32_t*);
+#else
 
 int ZK_CAT(msm_plan_create_, ZK_GROUP)(uint64_t n, const void* bases, int on_device, int flags, int window_bits,
                                        MsmPlanBase** out) {
@@ -27,5 +46,7 @@ int ZK_CAT(msm_batch_mul_, ZK_GROUP)(uint64_t n, const uint64_t* scalars, const 
                                      uint64_t* out) {
     return batch_mul_impl<ZK_GROUP>(n, scalars, bases, broadcast, out);
 }
+
+#endif
 
 }  // namespace zkmi

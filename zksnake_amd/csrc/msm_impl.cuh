@@ -112,6 +112,12 @@ __device__ __forceinline__ XYZZ<F> lds_get_xyzz(const uint32_t* slot) {
     return r;
 }
 
+// Buckets with more than COMBINE_SMALL_MAX runs (skewed scalars: e.g. the short top window, or many equal
+// scalars) are listed in big_list and reduced by a whole workgroup each instead of one lane.
+constexpr uint32_t COMBINE_SMALL_MAX = 16;    // <= 16 runs: one lane adds them up
+constexpr uint32_t COMBINE_WAVE_MAX = 2048;   // <= 2048 runs: one wave per bucket; above: one workgroup
+
+#if !defined(ZK_PART) || ZK_PART == 0  // sort-stage kernels and the plan live in part 0 only
 // ---- 1. digits -----------------------------------------------------------------------------------
 
 struct DigitBias {
@@ -199,10 +205,6 @@ static __global__ void prefix_kernel(uint32_t* __restrict__ hist, int group_size
 // The sorted entry list is cut into uniform segments of seg_len entries (one lane each), whatever the bucket
 // sizes are.  A "run" is the part of one bucket inside one segment; bucket `key` owns
 //   nruns = 1 + (last_entry / seg_len) - (first_entry / seg_len)   consecutive partial slots.
-// Buckets with more than COMBINE_SMALL_MAX runs (skewed scalars: e.g. the short top window, or many equal
-// scalars) are listed in big_list and reduced by a whole workgroup each instead of one lane.
-constexpr uint32_t COMBINE_SMALL_MAX = 16;    // <= 16 runs: one lane adds them up
-constexpr uint32_t COMBINE_WAVE_MAX = 2048;   // <= 2048 runs: one wave per bucket; above: one workgroup
 static __global__ void runs_kernel(const uint32_t* __restrict__ bucket_start, uint32_t n_keys, uint32_t seg_len,
                                    uint32_t* __restrict__ nruns, uint32_t* __restrict__ big_list,
                                    uint32_t* __restrict__ big_count) {
@@ -396,6 +398,8 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_range_kernel(cons
         }
     }
 }
+
+#endif  // ZK_PART == 0
 
 // ---- 5. accumulate (dominant kernel) ----------------------------------------------------------------
 
@@ -666,6 +670,20 @@ __global__ __launch_bounds__(128) void batch_mul_kernel(const uint32_t* __restri
     store_words<AW>(out + i * AW, w);
 }
 
+#if defined(ZK_GROUP) && (!defined(ZK_PART) || ZK_PART == 0)
+// the plan's translation unit does not instantiate the heavy kernels (see msm_group.hip)
+extern template __global__ void accumulate_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*);
+extern template __global__ void precompute_kernel<ZK_GROUP>(uint32_t*, uint32_t, int, int);
+extern template __global__ void batch_mul_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, int, uint64_t, uint32_t*);
+extern template __global__ void bases_to_mont_kernel<ZK_GROUP>(const uint32_t*, uint64_t, uint32_t*);
+extern template __global__ void combine_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, uint32_t, uint32_t*);
+extern template __global__ void combine_wave_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*);
+extern template __global__ void combine_big_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const uint32_t*, uint32_t*);
+extern template __global__ void strided_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t*, SumJob, SumJob, uint32_t);
+extern template __global__ void weighted_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t, uint32_t, const uint32_t*, uint32_t, uint32_t*);
+#endif
+
+#if !defined(ZK_PART) || ZK_PART == 0
 // ---- host: plan --------------------------------------------------------------------------------------
 
 static int pick_window_bits(uint64_t n) {
@@ -1056,5 +1074,7 @@ static int batch_mul_impl(uint64_t n, const uint64_t* scalars, const uint64_t* b
     return rc;
 }
 
+
+#endif  // ZK_PART == 0
 
 }  // namespace zkmi
