@@ -454,6 +454,12 @@ struct FpOps {
     static ZK_HD T one() { return fp_one<P>(); }
     static ZK_HD T add(const T& a, const T& b) { return fp_add<P>(a, b); }
     static ZK_HD T sub(const T& a, const T& b) { return fp_sub<P>(a, b); }
+    // a - b for immediate use as ONE operand of mul(): carry-free when the column accumulators have the room
+    // (N * 2^31 * 2^29 + N * 2^58 < 2^64, i.e. N <= 12), the ordinary subtraction otherwise
+    static ZK_HD T sub_for_mul(const T& a, const T& b) {
+        if constexpr (P::N <= 12) return fp_sub_lazy<P>(a, b);
+        else return fp_sub<P>(a, b);
+    }
     static ZK_HD T mul(const T& a, const T& b) { return fp_mul<P>(a, b); }
     static ZK_HD T sqr(const T& a) { return fp_sqr<P>(a); }
     static ZK_HD T neg(const T& a) { return fp_neg<P>(a); }
@@ -477,6 +483,7 @@ struct Fp2Ops {
     static ZK_HD T one() { return fp2_one<P>(); }
     static ZK_HD T add(const T& a, const T& b) { return fp2_add<P>(a, b); }
     static ZK_HD T sub(const T& a, const T& b) { return fp2_sub<P>(a, b); }
+    static ZK_HD T sub_for_mul(const T& a, const T& b) { return fp2_sub<P>(a, b); }  // fp_mul2 has no spare room
     static ZK_HD T mul(const T& a, const T& b) { return fp2_mul<P>(a, b); }
     static ZK_HD T sqr(const T& a) { return fp2_sqr<P>(a); }
     static ZK_HD T neg(const T& a) { return fp2_neg<P>(a); }
