@@ -158,6 +158,11 @@ int zk_point_compress(int curve, int group, const uint64_t* a, uint8_t* out);
 int zk_point_decompress(int curve, int group, const uint8_t* in, uint64_t* out);
 int zk_point_bytes(int curve, int group);
 
+/* pairing / multi_pairing (src/bn254/curve.rs:417-437): out = prod_i e(g1[i], g2[i]) after the final exponentiation,
+ * as 12 base-field elements (coefficients of 1, w, .., w^5 over Fp2; zk_gt_limbs 64-bit limbs).  Host only. */
+int zk_gt_limbs(int curve);
+int zk_multi_pairing(int curve, uint64_t n, const uint64_t* g1_points, const uint64_t* g2_points, uint64_t* out);
+
 /* ---- scalar-field host helpers (setup/verify side; polynomial.rs:518-533,636-652) -------- */
 
 int zk_fr_root_of_unity(int curve, uint64_t n, uint64_t* out);                 /* get_evaluation_point(n, 1) */
