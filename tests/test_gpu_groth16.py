@@ -178,3 +178,55 @@ def test_groth16_from_circom_poseidon(gpu):
     proof = g.prove(pub, priv)
     assert g.verify(proof, pub)
     assert not g.verify(proof, [pub[0], (pub[1] + 1) % r1cs.p])
+
+
+def _sharded_prove_worker(rank, world, port, curve, log_n, q):
+    """one rank of a window-sharded prove; all ranks share the box's single GPU and exchange over gloo"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        cv = pyref.curve_by_name(curve)
+        n = 1 << log_n
+        A, B, C, w, n_col = W.chain_circuit(n, cv.r)
+        g = Groth16(R1CS.from_triplets(A, B, C, n, n_col, 2, curve), curve)
+        g._toxic, g._blinding = TOXIC, BLIND
+        g.setup()
+        g.shard_over_ranks()
+        proof = g.prove(N.ints_to_limbs(w[:2]), N.ints_to_limbs(w[2:]))
+        g._blinding = None  # drawn on rank 0 and broadcast: all ranks still agree
+        proof_r = g.prove(w[:2], w[2:])
+        q.put((rank, proof.to_bytes().hex(), bool(g.verify(proof_r, w[:2])), proof_r.to_bytes().hex()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("curve,world", [("BN254", 2), ("BLS12_381", 3)])
+def test_window_sharded_prove_two_and_three_ranks(gpu, curve, world):
+    """SURVEY 8e / BASELINE config 5 shape: every rank runs its windows of the five MSMs, one all_gather of the
+    partial points, identical proof bytes on every rank = the closed form.  (RCCL needs one GPU per rank, so the
+    one-GPU box exchanges over gloo; the exchange code is the same.)"""
+    import socket
+    import torch.multiprocessing as mp
+    cv = pyref.curve_by_name(curve)
+    log_n = 10
+    n = 1 << log_n
+    A, B, C, w, n_col = W.chain_circuit(n, cv.r)
+    exp = _oracle_proof_bytes((list(zip(*A)), list(zip(*B)), list(zip(*C)), n, n_col, 2, w), cv).hex()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_prove_worker, args=(r, world, port, curve, log_n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[0] for r in results] == list(range(world))
+    assert all(r[1] == exp for r in results), "sharded proof differs from the closed form"
+    assert all(r[2] for r in results) and len({r[3] for r in results}) == 1

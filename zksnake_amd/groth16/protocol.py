@@ -9,6 +9,10 @@ and the five MSM results on the GPU:
 
 The proving key vectors are `PointArray`s whose Montgomery-form bases stay resident in HBM
 (MSM plans), so a prove moves one witness up and three points down.
+
+Multi-GPU (BASELINE config 5): after `shard_over_ranks()` every rank evaluates the QAP
+(replicated, ~1.5 ms at 2^20) and runs only ITS windows of the five MSMs; the five partial points of all
+ranks travel in one all_gather (RCCL) and every rank assembles the same proof.
 """
 
 import numpy as np
@@ -43,6 +47,7 @@ class Groth16:
         self._blinding = None   # tests may pin (r, s)
         self.precompute_keys = True  # proving-key MSM plans use the fixed-base table (ZK_MSM_PRECOMPUTE)
         self.last_timings = {}
+        self._shard = None      # (rank, world, torch device or None) once shard_over_ranks() was called
 
     # ------------------------------------------------------------------------------------------
     def setup(self):
@@ -88,21 +93,53 @@ class Groth16:
         self.verifying_key = VerifyingKey(alpha_G1, beta_G2, gamma_G2, delta_G2, k_gamma_G1)
 
     # ------------------------------------------------------------------------------------------
+    def shard_over_ranks(self, device=None):
+        """split the windows of every MSM in prove() over the ranks of the default torch.distributed group
+        (one process per GPU; backend nccl = RCCL, or gloo).  `device` is where the gathered partial points
+        are staged (the rank's GPU for RCCL, None for gloo)."""
+        import torch.distributed as dist
+        self._shard = (dist.get_rank(), dist.get_world_size(), device)
+
     def _enqueue_msm(self, bases, group, d_scalars, count, slot=0):
-        """start <bases[:count], scalars> (scalars already in HBM) on the plan's own stream"""
+        """start <bases[:count], scalars> (scalars already in HBM) on the plan's own stream; with sharding only
+        this rank's windows.  Returns (array, handle); handle None = this rank has no window of that MSM."""
         lib = N.load()
         arr = _as_array(self.E, bases, group)
         handle = arr.plan(slot, precompute=self.precompute_keys)
-        N.check(lib.zk_msm_plan_enqueue(handle, count, d_scalars, 1, 0, 0, N.STREAM_PLAN))
+        first, cnt = 0, 0  # 0, 0 = all windows
+        if self._shard is not None and self._shard[1] > 1:
+            from ..parallel import window_ranges
+            c, nwin = N.ctypes.c_int(0), N.ctypes.c_int(0)
+            N.check(lib.zk_msm_plan_windows(handle, c, nwin))
+            first, cnt = window_ranges(nwin.value, self._shard[1])[self._shard[0]]
+            if cnt == 0:
+                return arr, None
+        N.check(lib.zk_msm_plan_enqueue(handle, count, d_scalars, 1, first, cnt, N.STREAM_PLAN))
         return arr, handle
 
     def _finish_msm(self, handle, group):
+        """affine limbs of the (partial) MSM result; all-zero = infinity"""
         lib = N.load()
-        cid = self.E.curve.curve_id
-        out = np.zeros(N.point_limbs(cid, group), dtype=np.uint64)
-        N.check(lib.zk_msm_plan_finish(handle, N.u64p(out)))
+        out = np.zeros(N.point_limbs(self.E.curve.curve_id, group), dtype=np.uint64)
+        if handle is not None:
+            N.check(lib.zk_msm_plan_finish(handle, N.u64p(out)))
+        return out
+
+    def _exchange(self, parts):
+        """parts: [(limbs, group)] partial points of this rank -> totals over all ranks, as points"""
         from .._algebra import _point_class
-        return _point_class(cid, group)._from_limbs(out)
+        cid = self.E.curve.curve_id
+        if self._shard is not None and self._shard[1] > 1:
+            from ..parallel import all_gather_limbs, sum_points
+            flat = np.concatenate([p for p, _ in parts])
+            gathered = all_gather_limbs(flat, self._shard[2])  # (world, len)
+            totals, off = [], 0
+            for p, group in parts:
+                totals.append(sum_points(cid, group, list(gathered[:, off:off + p.shape[0]])))
+                off += p.shape[0]
+        else:
+            totals = [p for p, _ in parts]
+        return [_point_class(cid, group)._from_limbs(t) for t, (_, group) in zip(totals, parts)]
 
     def prove(self, public_witness, private_witness) -> Proof:
         """public_witness / private_witness: lists of ints (reference API) or (k, 4) uint64 limb arrays."""
@@ -114,6 +151,11 @@ class Groth16:
             r, s = self._blinding
         else:
             r, s = get_random_int(q - 1), get_random_int(q - 1)
+            if self._shard is not None and self._shard[1] > 1:  # every rank assembles the same proof
+                import torch.distributed as dist
+                box = [(r, s)]
+                dist.broadcast_object_list(box, src=0)
+                r, s = box[0]
 
         if isinstance(public_witness, np.ndarray) or isinstance(private_witness, np.ndarray):
             pub = public_witness if isinstance(public_witness, np.ndarray) else N.ints_to_limbs(public_witness, 4, q)
@@ -138,11 +180,9 @@ class Groth16:
         h_k = None
         if n_priv > 0:
             pk.kdelta_1, h_k = self._enqueue_msm(pk.kdelta_1, 1, res.witness.ptr + 32 * n_pub, n_priv)
-        msm_u = self._finish_msm(h_u, 1)
-        msm_v2 = self._finish_msm(h_v2, 2)
-        msm_v1 = self._finish_msm(h_v1, 1)
-        HZ = self._finish_msm(h_h, 1)
-        sum_delta_witness = self._finish_msm(h_k, 1) if h_k is not None else self.E.G1() * 0
+        parts = [(self._finish_msm(h_u, 1), 1), (self._finish_msm(h_v2, 2), 2), (self._finish_msm(h_v1, 1), 1),
+                 (self._finish_msm(h_h, 1), 1), (self._finish_msm(h_k, 1), 1)]
+        msm_u, msm_v2, msm_v1, HZ, sum_delta_witness = self._exchange(parts)
 
         A = msm_u + pk.alpha_1 + pk.delta_1 * r
         B1 = msm_v1 + pk.beta_1 + pk.delta_1 * s

@@ -31,14 +31,14 @@ def sum_points(curve_id, group, partials):
     return out
 
 
-def all_gather_sum(curve_id, group, partial, device=None):
-    """all ranks contribute one partial point (uint64 limbs) and receive the total.
+def all_gather_limbs(mine, device=None):
+    """every rank contributes a flat uint64 vector of the same length; returns the (world, len) array.
     Uses the default torch.distributed process group (RCCL on GPUs, gloo on CPU)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size()
-    mine = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).view(np.int64))
+    mine = torch.from_numpy(np.ascontiguousarray(mine, dtype=np.uint64).view(np.int64))
     if device is not None:
         mine = mine.to(device)
     gathered = torch.zeros((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
@@ -48,4 +48,9 @@ def all_gather_sum(curve_id, group, partial, device=None):
         bucket = list(gathered.unbind(0))
         dist.all_gather(bucket, mine)
         gathered = torch.stack(bucket)
-    return sum_points(curve_id, group, list(gathered.cpu().numpy().view(np.uint64)))
+    return gathered.cpu().numpy().view(np.uint64)
+
+
+def all_gather_sum(curve_id, group, partial, device=None):
+    """all ranks contribute one partial point (uint64 limbs) and receive the total"""
+    return sum_points(curve_id, group, list(all_gather_limbs(partial, device)))
