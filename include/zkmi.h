@@ -158,6 +158,18 @@ int zk_point_compress(int curve, int group, const uint64_t* a, uint8_t* out);
 int zk_point_decompress(int curve, int group, const uint8_t* in, uint64_t* out);
 int zk_point_bytes(int curve, int group);
 
+/* Dense-polynomial helpers over Fr used by the PlonK prover (python/zksnake/plonk/protocol.py:157-484); canonical
+ * coefficients, lowest degree first, host memory.  They replace Polynomial.__call__ (src/bn254/polynomial.rs:491-516),
+ * Polynomial.__truediv__ by a linear factor (:404-438), the batch_modinv + accumulator loop of protocol.py:296-307 and
+ * Polynomial scalar-multiply-add chains (:319-402). */
+int zk_fr_poly_eval(int curve, uint64_t n, const uint64_t* coeffs, const uint64_t* x, uint64_t* out);
+/* coeffs (n) = q (n - 1 entries) * (X - root) + rem (1 entry) */
+int zk_fr_poly_div_linear(int curve, uint64_t n, const uint64_t* coeffs, const uint64_t* root, uint64_t* q, uint64_t* rem);
+/* out (n + 1 entries): out[0] = 1, out[i+1] = out[i] * num[i] / den[i]; ZK_ERR_ARG on a zero denominator */
+int zk_fr_grand_product(int curve, uint64_t n, const uint64_t* num, const uint64_t* den, uint64_t* out);
+/* acc[i] += s * x[i], i < n */
+int zk_fr_scale_add(int curve, uint64_t n, uint64_t* acc, const uint64_t* x, const uint64_t* s);
+
 /* pairing / multi_pairing (src/bn254/curve.rs:417-437): out = prod_i e(g1[i], g2[i]) after the final exponentiation,
  * as 12 base-field elements (coefficients of 1, w, .., w^5 over Fp2; zk_gt_limbs 64-bit limbs).  Host only. */
 int zk_gt_limbs(int curve);

@@ -77,6 +77,10 @@ SIGNATURES = {
     "zk_point_compress": (_i, [_i, _i, _u64p, _u8p]),
     "zk_point_decompress": (_i, [_i, _i, _u8p, _u64p]),
     "zk_point_bytes": (_i, [_i, _i]),
+    "zk_fr_poly_eval": (_i, [_i, _u64, _u64p, _u64p, _u64p]),
+    "zk_fr_poly_div_linear": (_i, [_i, _u64, _u64p, _u64p, _u64p, _u64p]),
+    "zk_fr_grand_product": (_i, [_i, _u64, _u64p, _u64p, _u64p]),
+    "zk_fr_scale_add": (_i, [_i, _u64, _u64p, _u64p, _u64p]),
     "zk_gt_limbs": (_i, [_i]),
     "zk_multi_pairing": (_i, [_i, _u64, _u64p, _u64p, _u64p]),
     "zk_fr_root_of_unity": (_i, [_i, _u64, _u64p]),

@@ -2,6 +2,7 @@
 R1CS; the symbolic constraint DSL `Var`/`ConstraintSystem` of the reference is a front end outside the
 accelerated path)."""
 
+from .plonkish import Plonkish
 from .r1cs import R1CS
 
-__all__ = ["R1CS"]
+__all__ = ["R1CS", "Plonkish"]

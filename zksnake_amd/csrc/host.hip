@@ -268,6 +268,75 @@ static int lagrange_impl(uint64_t n_in, const uint64_t* tau_c, uint64_t* out) {
     return ZK_OK;
 }
 
+// ---- dense-polynomial helpers over Fr for the PlonK prover (host, O(n) sequential recurrences) ----
+template <class P>
+static int poly_eval_impl(uint64_t n, const uint64_t* coeffs, const uint64_t* x_c, uint64_t* out) {
+    const uint32_t* c = reinterpret_cast<const uint32_t*>(coeffs);
+    Fp<P> x = fp_from_canonical<P>(reinterpret_cast<const uint32_t*>(x_c));
+    Fp<P> acc = fp_zero<P>();
+    for (uint64_t i = n; i-- > 0;) acc = fp_add<P>(fp_mul<P>(acc, x), fp_from_canonical<P>(c + i * P::W));
+    fp_to_canonical<P>(reinterpret_cast<uint32_t*>(out), acc);
+    return ZK_OK;
+}
+
+// coeffs (n) = q (n - 1) * (X - root) + rem
+template <class P>
+static int poly_div_linear_impl(uint64_t n, const uint64_t* coeffs, const uint64_t* root_c, uint64_t* q, uint64_t* rem) {
+    const uint32_t* c = reinterpret_cast<const uint32_t*>(coeffs);
+    uint32_t* qo = reinterpret_cast<uint32_t*>(q);
+    Fp<P> root = fp_from_canonical<P>(reinterpret_cast<const uint32_t*>(root_c));
+    Fp<P> carry = fp_zero<P>();
+    for (uint64_t i = n; i-- > 1;) {
+        carry = fp_add<P>(fp_from_canonical<P>(c + i * P::W), fp_mul<P>(carry, root));
+        fp_to_canonical<P>(qo + (i - 1) * P::W, carry);
+    }
+    Fp<P> r0 = n ? fp_add<P>(fp_from_canonical<P>(c), fp_mul<P>(carry, root)) : fp_zero<P>();
+    fp_to_canonical<P>(reinterpret_cast<uint32_t*>(rem), r0);
+    return ZK_OK;
+}
+
+// out[0] = 1, out[i + 1] = out[i] * num[i] / den[i]   (one field inversion in total)
+template <class P>
+static int grand_product_impl(uint64_t n, const uint64_t* num, const uint64_t* den, uint64_t* out) {
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(num);
+    const uint32_t* b = reinterpret_cast<const uint32_t*>(den);
+    uint32_t* o = reinterpret_cast<uint32_t*>(out);
+    std::vector<Fp<P>> d(n), pre(n);
+    Fp<P> run = fp_one<P>();
+    for (uint64_t i = 0; i < n; ++i) {
+        d[i] = fp_from_canonical<P>(b + i * P::W);
+        if (fp_is_zero<P>(d[i])) return fail(ZK_ERR_ARG, "grand product: zero denominator");
+        pre[i] = run;
+        run = fp_mul<P>(run, d[i]);
+    }
+    Fp<P> inv = fp_inv<P>(run);
+    for (uint64_t i = n; i-- > 0;) {  // d[i] <- 1 / den[i]
+        Fp<P> di = fp_mul<P>(inv, pre[i]);
+        inv = fp_mul<P>(inv, d[i]);
+        d[i] = di;
+    }
+    Fp<P> acc = fp_one<P>();
+    fp_to_canonical<P>(o, acc);
+    for (uint64_t i = 0; i < n; ++i) {
+        acc = fp_mul<P>(fp_mul<P>(acc, fp_from_canonical<P>(a + i * P::W)), d[i]);
+        fp_to_canonical<P>(o + (i + 1) * P::W, acc);
+    }
+    return ZK_OK;
+}
+
+// acc[i] += s * x[i] for i < n
+template <class P>
+static int scale_add_impl(uint64_t n, uint64_t* acc, const uint64_t* x, const uint64_t* s_c) {
+    uint32_t* a = reinterpret_cast<uint32_t*>(acc);
+    const uint32_t* xs = reinterpret_cast<const uint32_t*>(x);
+    Fp<P> s = fp_from_canonical<P>(reinterpret_cast<const uint32_t*>(s_c));
+    for (uint64_t i = 0; i < n; ++i) {
+        Fp<P> v = fp_add<P>(fp_from_canonical<P>(a + i * P::W), fp_mul<P>(s, fp_from_canonical<P>(xs + i * P::W)));
+        fp_to_canonical<P>(a + i * P::W, v);
+    }
+    return ZK_OK;
+}
+
 static int g_device = -1;
 
 }  // namespace zkmi
@@ -432,6 +501,30 @@ int zk_fr_root_of_unity(int curve, uint64_t n, uint64_t* out) {
 
 int zk_fr_lagrange_coeffs(int curve, uint64_t n, const uint64_t* tau, uint64_t* out) {
 #define CALL(P) return lagrange_impl<P>(n, tau, out)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_fr_poly_eval(int curve, uint64_t n, const uint64_t* coeffs, const uint64_t* x, uint64_t* out) {
+#define CALL(P) return poly_eval_impl<P>(n, coeffs, x, out)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_fr_poly_div_linear(int curve, uint64_t n, const uint64_t* coeffs, const uint64_t* root, uint64_t* q, uint64_t* rem) {
+#define CALL(P) return poly_div_linear_impl<P>(n, coeffs, root, q, rem)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_fr_grand_product(int curve, uint64_t n, const uint64_t* num, const uint64_t* den, uint64_t* out) {
+#define CALL(P) return grand_product_impl<P>(n, num, den, out)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_fr_scale_add(int curve, uint64_t n, uint64_t* acc, const uint64_t* x, const uint64_t* s) {
+#define CALL(P) return scale_add_impl<P>(n, acc, x, s)
     ZK_DISPATCH_FR(curve, CALL);
 #undef CALL
 }

@@ -1,0 +1,120 @@
+"""
+Vectors of scalar-field elements as (n, 4) uint64 limb arrays (canonical, little-endian) and the
+library calls the PlonK prover needs on them: GPU transforms and element-wise ops (zk_ntt, zk_vec_op),
+host O(n) recurrences (zk_fr_poly_eval / _div_linear / _grand_product / _scale_add).  Python integers
+appear only for single field elements (challenges, evaluations), never per coefficient.
+"""
+
+import numpy as np
+
+from . import _native as N
+from .constant import BLS12_381_SCALAR_FIELD, BN254_SCALAR_FIELD
+
+_CID = {BN254_SCALAR_FIELD: N.CURVE_BN254, BLS12_381_SCALAR_FIELD: N.CURVE_BLS12_381}
+
+
+class FrOps:
+    def __init__(self, modulus):
+        self.r = modulus
+        self.cid = _CID[modulus]
+
+    # -- conversions --
+    def limbs(self, values):
+        """list[int] | (n, 4) uint64 -> (n, 4) uint64 (ints reduced mod r)"""
+        if isinstance(values, np.ndarray):
+            return np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 4)
+        return N.ints_to_limbs(values, 4, self.r)
+
+    def one(self, value):
+        return N.ints_to_limbs([value % self.r], 4)
+
+    def ints(self, arr):
+        return N.limbs_to_ints(arr)
+
+    def int_at(self, arr, i):
+        return int.from_bytes(arr[i].tobytes(), "little")
+
+    def add_at(self, arr, i, value):
+        """arr[i] += value (mod r), in place"""
+        arr[i] = np.frombuffer(((self.int_at(arr, i) + value) % self.r).to_bytes(32, "little"), dtype=np.uint64)
+
+    def const(self, value, n):
+        return np.tile(self.one(value), (n, 1))
+
+    def zeros(self, n):
+        return np.zeros((n, 4), dtype=np.uint64)
+
+    @staticmethod
+    def strip(arr):
+        """drop trailing zero coefficients"""
+        nz = np.flatnonzero(arr.any(axis=1))
+        return arr[: (int(nz[-1]) + 1 if nz.size else 0)]
+
+    # -- GPU --
+    def ntt(self, vals, size, inverse=False, coset=False):
+        lib = N.ensure_gpu()
+        a = self.limbs(vals)
+        n = 1 if size <= 1 else 1 << (size - 1).bit_length()
+        out = np.zeros((n, 4), dtype=np.uint64)
+        st = lib.zk_ntt(self.cid, int(inverse), int(coset), a.shape[0], N.u64p(a), size, N.u64p(out))
+        if st == N.ZK_ERR_DOMAIN:
+            raise ValueError("Domain size is too large")
+        N.check(st)
+        return out
+
+    def _vec(self, op, a, b):
+        lib = N.ensure_gpu()
+        assert a.shape == b.shape, "element-wise operands differ in length"
+        out = np.zeros_like(a)
+        if a.shape[0]:
+            N.check(lib.zk_vec_op(self.cid, op, a.shape[0], a.shape[0], N.u64p(a), b.shape[0], N.u64p(b), N.u64p(out)))
+        return out
+
+    def mul(self, a, b):
+        return self._vec(0, a, b)
+
+    def add(self, a, b):
+        return self._vec(1, a, b)
+
+    def sub(self, a, b):
+        return self._vec(2, a, b)
+
+    def powers(self, g, count):
+        """(1, g, g^2, ..) by doubling: log2(count) element-wise products"""
+        pw = self.limbs([1])
+        while pw.shape[0] < count:
+            k = pw.shape[0]
+            pw = np.concatenate([pw, self.mul(pw, self.const(pow(g, k, self.r), k))])
+        return np.ascontiguousarray(pw[:count])
+
+    # -- host recurrences --
+    def eval(self, coeffs, x):
+        lib = N.load()
+        out = np.zeros(4, dtype=np.uint64)
+        c = np.ascontiguousarray(coeffs)
+        N.check(lib.zk_fr_poly_eval(self.cid, c.shape[0], N.u64p(c), N.u64p(self.one(x)), N.u64p(out)))
+        return int.from_bytes(out.tobytes(), "little")
+
+    def div_linear(self, coeffs, root):
+        """(quotient limbs, remainder int) of coeffs / (X - root)"""
+        lib = N.load()
+        c = np.ascontiguousarray(coeffs)
+        q = np.zeros((max(c.shape[0] - 1, 1), 4), dtype=np.uint64)
+        rem = np.zeros(4, dtype=np.uint64)
+        N.check(lib.zk_fr_poly_div_linear(self.cid, c.shape[0], N.u64p(c), N.u64p(self.one(root)), N.u64p(q), N.u64p(rem)))
+        return q[: max(c.shape[0] - 1, 0)], int.from_bytes(rem.tobytes(), "little")
+
+    def grand_product(self, num, den):
+        lib = N.load()
+        out = np.zeros((num.shape[0] + 1, 4), dtype=np.uint64)
+        N.check(lib.zk_fr_grand_product(self.cid, num.shape[0], N.u64p(np.ascontiguousarray(num)),
+                                        N.u64p(np.ascontiguousarray(den)), N.u64p(out)))
+        return out
+
+    def scale_add(self, acc, x, s):
+        """acc[:len(x)] += s * x, in place (acc must be at least as long as x)"""
+        lib = N.load()
+        assert acc.shape[0] >= x.shape[0] and acc.flags["C_CONTIGUOUS"]
+        if x.shape[0]:
+            N.check(lib.zk_fr_scale_add(self.cid, x.shape[0], N.u64p(acc), N.u64p(np.ascontiguousarray(x)), N.u64p(self.one(s))))
+        return acc
