@@ -78,5 +78,28 @@ def chain_circuit(n, modulus, inp=2):
     return A, B, C, w, 3 + nv
 
 
+def plonk_chain_gates(n, modulus, inp=2):
+    """PlonK form of the same chain (n a power of two >= 2): rows i < n-1 are a*b - c = 0 with a_0 = b_i = inp,
+    a_{i+1} = c_i; row n-1 is a - out = 0 with `out` public.  Returns (selector columns dict L,R,O,M,C,
+    slot permutation over [a | b | c], public dict {row: -out}, flat private witness [a0, b0, c0, a1, ..])."""
+    assert n >= 2 and n & (n - 1) == 0
+    r = modulus
+    vals, cur = [], inp % r
+    for _ in range(n - 1):
+        cur = cur * inp % r
+        vals.append(cur)
+    a = [inp % r] + vals[:-1] + [vals[-1]]
+    b = [inp % r] * (n - 1) + [0]
+    c = vals + [0]
+    gates = {"L": [0] * (n - 1) + [1], "R": [0] * n, "O": [r - 1] * (n - 1) + [0], "M": [1] * (n - 1) + [0], "C": [0] * n}
+    perm = np.arange(3 * n, dtype=np.int64)
+    ring = np.concatenate([[0], n + np.arange(n - 1)])        # a_0 and every live b_i carry `inp`
+    perm[ring] = np.roll(ring, -1)
+    i = np.arange(n - 1)
+    perm[2 * n + i], perm[i + 1] = i + 1, 2 * n + i           # c_i <-> a_{i+1}
+    private = [x for row in zip(a, b, c) for x in row]
+    return gates, perm.tolist(), {n - 1: (-vals[-1]) % r}, private
+
+
 def scalar_field(curve):
     return constant.BN254_SCALAR_FIELD if curve in ("BN254", "BN128", "ALT_BN128") else constant.BLS12_381_SCALAR_FIELD
