@@ -158,6 +158,28 @@ int zk_point_compress(int curve, int group, const uint64_t* a, uint8_t* out);
 int zk_point_decompress(int curve, int group, const uint8_t* in, uint64_t* out);
 int zk_point_bytes(int curve, int group);
 
+/* ---- PlonK prover, device-resident vector kernels (csrc/plonk.hip) ----
+ * They replace the element-wise polynomial arithmetic of Plonk.prove (python/zksnake/plonk/protocol.py:213-460: chains of
+ * fft / mul_over_evaluation_domain / add_over_evaluation_domain, Polynomial scalar multiply-adds, Polynomial.__call__).
+ * Vectors are canonical Fr elements in device memory; scalars are canonical 4-limb integers in host memory. */
+/* out = a*x + b*y + c (element-wise; b and d_y may both be NULL, c may be NULL); out may alias x or y */
+int zk_vec_axpby_dev(int curve, uint64_t n, const uint64_t* a, const void* d_x, const uint64_t* b, const void* d_y, const uint64_t* c,
+                     void* d_out, void* stream);
+/* *is_zero = 1 when all n elements are zero (synchronises the stream) */
+int zk_vec_is_zero_dev(int curve, uint64_t n, const void* d_x, int* is_zero, void* stream);
+/* out = sum_i coeffs[i] x^i (Polynomial.__call__, src/bn254/polynomial.rs:491-516); synchronises the stream */
+int zk_poly_eval_dev(int curve, uint64_t n, const void* d_coeffs, const uint64_t* x, uint64_t* out, void* stream);
+/* out[i] = prod_{j<3} (wires[j][i] + beta*labels[j][i] + gamma): numerator / denominator terms of the grand product
+ * (protocol.py:270-292), labels = the identity or the sigma columns on the n-domain */
+int zk_plonk_perm_terms_dev(int curve, uint64_t n, const void* const* d_wires, const void* const* d_labels, const uint64_t* beta,
+                            const uint64_t* gamma, void* d_out, void* stream);
+/* Quotient evaluations on a coset of size m = k*n (2 <= k <= 16) (protocol.py:309-347 evaluated pointwise):
+ * out = [gate + alpha*(prod(w_j + beta*k_j*x + gamma)*z - prod(w_j + beta*sigma_j + gamma)*z(omega x)) + alpha^2*(z - 1)*L1] / (x^n - 1)
+ * d_cols = 15 vectors of m elements: a, b, c, z, PI, qL, qR, qO, qM, qC, sigma1, sigma2, sigma3, x (the coset points), L1;
+ * z(omega x) is read from z at index (i + k) mod m; zh_inv = the k distinct values of 1/(x^n - 1) (host, canonical). */
+int zk_plonk_quotient_dev(int curve, uint64_t m, uint64_t n, const void* const* d_cols, const uint64_t* zh_inv, const uint64_t* beta,
+                          const uint64_t* gamma, const uint64_t* alpha, void* d_out, void* stream);
+
 /* Dense-polynomial helpers over Fr used by the PlonK prover (python/zksnake/plonk/protocol.py:157-484); canonical
  * coefficients, lowest degree first, host memory.  They replace Polynomial.__call__ (src/bn254/polynomial.rs:491-516),
  * Polynomial.__truediv__ by a linear factor (:404-438), the batch_modinv + accumulator loop of protocol.py:296-307 and

@@ -77,6 +77,11 @@ SIGNATURES = {
     "zk_point_compress": (_i, [_i, _i, _u64p, _u8p]),
     "zk_point_decompress": (_i, [_i, _i, _u8p, _u64p]),
     "zk_point_bytes": (_i, [_i, _i]),
+    "zk_vec_axpby_dev": (_i, [_i, _u64, _u64p, _vp, _u64p, _vp, _u64p, _vp, _vp]),
+    "zk_vec_is_zero_dev": (_i, [_i, _u64, _vp, ctypes.POINTER(_i), _vp]),
+    "zk_poly_eval_dev": (_i, [_i, _u64, _vp, _u64p, _u64p, _vp]),
+    "zk_plonk_perm_terms_dev": (_i, [_i, _u64, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _u64p, _u64p, _vp, _vp]),
+    "zk_plonk_quotient_dev": (_i, [_i, _u64, _u64, ctypes.POINTER(_vp), _u64p, _u64p, _u64p, _u64p, _vp, _vp]),
     "zk_fr_poly_eval": (_i, [_i, _u64, _u64p, _u64p, _u64p]),
     "zk_fr_poly_div_linear": (_i, [_i, _u64, _u64p, _u64p, _u64p, _u64p]),
     "zk_fr_grand_product": (_i, [_i, _u64, _u64p, _u64p, _u64p]),

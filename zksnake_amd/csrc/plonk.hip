@@ -1,0 +1,285 @@
+// plonk.hip -- device-resident vector kernels of the PlonK prover over BN254 Fr / BLS12-381 Fr (gfx950).
+//
+// Stands in for the element-wise polynomial arithmetic of Plonk.prove in the reference
+// (python/zksnake/plonk/protocol.py:213-460: fft -> mul_over_evaluation_domain / add_over_evaluation_domain
+// chains, Polynomial scalar multiply-adds, Polynomial.__call__), fused so that one proof makes one pass over
+// each coset-evaluation vector.  SURVEY.md 8f row 2.
+//
+// All vectors are canonical Fr elements (32 B) in HBM; scalars cross the ABI as canonical 4-limb integers.
+// Products use the Montgomery multiplier directly on canonical data: mont(x, s*R) = x*s, and chains of k
+// products of canonical values are corrected once by a scalar carrying R^k (folded into alpha below), so no
+// vector is ever converted to Montgomery form.
+//
+// Roofline: the quotient kernel reads 15 vectors and writes one (512 B per point) against 22 field products;
+// at ~1000 cycles per product per wave it is integer-multiply bound like everything else on this path.
+#include <vector>
+#include "common.cuh"
+#include "fr_mem.cuh"
+
+namespace zkmi {
+
+template <class P>
+__host__ Fp<P> scalar_in(const uint64_t* s) {
+    return fp_unpack<P>(reinterpret_cast<const uint32_t*>(s));  // canonical integer as limbs
+}
+
+// s * R^k as an integer (k >= 0): what mont() must be fed to undo k divisions by R
+template <class P>
+__host__ Fp<P> scalar_times_r(const uint64_t* s, int k) {
+    Fp<P> v = scalar_in<P>(s);
+    for (int i = 0; i < k; ++i) v = fp_mul<P>(v, fp_const<P>(P::R2));
+    return fp_reduce_full<P>(v);
+}
+
+// out = a*x + b*y + c      (y may be null)
+template <class P>
+__global__ __launch_bounds__(256) void axpby_kernel(uint64_t n, Fp<P> a_m, const uint32_t* __restrict__ x, Fp<P> b_m,
+                                                    const uint32_t* __restrict__ y, Fp<P> c, uint32_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp<P> v = fp_add<P>(fp_mul<P>(load_fr<P>(x + i * P::W), a_m), c);
+    if (y) v = fp_add<P>(v, fp_mul<P>(load_fr<P>(y + i * P::W), b_m));
+    store_fr<P>(out + i * P::W, fp_reduce_full<P>(v));
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void is_zero_kernel(uint64_t n_vec4, const uint4* __restrict__ x, int* flag) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_vec4) return;
+    uint4 t = x[i];
+    if (t.x | t.y | t.z | t.w) atomicOr(flag, 1);
+}
+
+// out[i] = prod_j (w_j[i] + beta * label_j[i] + gamma),  j = 0..2      (protocol.py:270-292 on the n-domain)
+template <class P>
+__global__ __launch_bounds__(256) void perm_terms_kernel(uint64_t n, const uint32_t* __restrict__ w0, const uint32_t* __restrict__ w1,
+                                                         const uint32_t* __restrict__ w2, const uint32_t* __restrict__ l0,
+                                                         const uint32_t* __restrict__ l1, const uint32_t* __restrict__ l2,
+                                                         Fp<P> beta_m, Fp<P> gamma, uint32_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t o = i * P::W;
+    Fp<P> u0 = fp_add<P>(fp_add<P>(load_fr<P>(w0 + o), fp_mul<P>(load_fr<P>(l0 + o), beta_m)), gamma);
+    Fp<P> u1 = fp_add<P>(fp_add<P>(load_fr<P>(w1 + o), fp_mul<P>(load_fr<P>(l1 + o), beta_m)), gamma);
+    Fp<P> u2 = fp_add<P>(fp_add<P>(load_fr<P>(w2 + o), fp_mul<P>(load_fr<P>(l2 + o), beta_m)), gamma);
+    const Fp<P> r2 = fp_const<P>(P::R2);
+    Fp<P> v = fp_mul<P>(fp_mul<P>(fp_mul<P>(u0, r2), u1), fp_mul<P>(u2, r2));  // (u0 R)(u1)/R = u0 u1; (u0 u1)(u2 R)/R
+    store_fr<P>(out + o, fp_reduce_full<P>(v));
+}
+
+constexpr int QUOT_MAX_PERIOD = 16;
+
+template <class P>
+struct QuotientArgs {
+    const uint32_t *a, *b, *c, *z, *pi, *ql, *qr, *qo, *qm, *qc, *s1, *s2, *s3, *x, *l1;
+    Fp<P> beta_m;    // beta R
+    Fp<P> gamma;     // gamma
+    Fp<P> alpha_r4;  // alpha R^4: closes a chain of four products of canonical values
+    Fp<P> alpha2_r2; // alpha^2 R^2
+    Fp<P> zh_inv_m[QUOT_MAX_PERIOD];  // 1/(x^n - 1) R for the m/n distinct values on the coset
+    uint32_t period;  // m / n
+};
+
+// t(x) = [ gate + alpha (prod(w_j + beta k_j x + gamma) z(x) - prod(w_j + beta sigma_j + gamma) z(omega x))
+//          + alpha^2 (z(x) - 1) L1(x) ] / (x^n - 1)      on the coset g*H_m  (protocol.py:309-347, evaluated pointwise)
+template <class P>
+__global__ __launch_bounds__(256) void quotient_kernel(uint64_t m, QuotientArgs<P> q, uint32_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const size_t o = i * P::W;
+    const Fp<P> r2 = fp_const<P>(P::R2);
+    Fp<P> a = load_fr<P>(q.a + o), b = load_fr<P>(q.b + o), c = load_fr<P>(q.c + o);
+    // gate: (a qL + b qR + c qO + (a b) qM) / R, then back to scale 1, then the constant column and PI
+    Fp<P> ab = fp_mul<P>(fp_mul<P>(a, b), r2);
+    Fp<P> g = fp_add<P>(fp_add<P>(fp_mul<P>(a, load_fr<P>(q.ql + o)), fp_mul<P>(b, load_fr<P>(q.qr + o))),
+                        fp_add<P>(fp_mul<P>(c, load_fr<P>(q.qo + o)), fp_mul<P>(ab, load_fr<P>(q.qm + o))));
+    g = fp_add<P>(fp_mul<P>(g, r2), fp_add<P>(load_fr<P>(q.qc + o), load_fr<P>(q.pi + o)));
+    // permutation argument
+    Fp<P> ag = fp_add<P>(a, q.gamma), bg = fp_add<P>(b, q.gamma), cg = fp_add<P>(c, q.gamma);
+    Fp<P> bx = fp_mul<P>(load_fr<P>(q.x + o), q.beta_m);
+    Fp<P> bx2 = fp_add<P>(bx, bx);
+    Fp<P> z = load_fr<P>(q.z + o);
+    Fp<P> left = fp_mul<P>(fp_mul<P>(fp_mul<P>(fp_mul<P>(fp_add<P>(ag, bx), fp_add<P>(bg, bx2)), fp_add<P>(cg, fp_add<P>(bx2, bx))), z), q.alpha_r4);
+    uint64_t iw = i + q.period;
+    if (iw >= m) iw -= m;
+    Fp<P> zw = load_fr<P>(q.z + iw * P::W);
+    Fp<P> t1 = fp_add<P>(ag, fp_mul<P>(load_fr<P>(q.s1 + o), q.beta_m));
+    Fp<P> t2 = fp_add<P>(bg, fp_mul<P>(load_fr<P>(q.s2 + o), q.beta_m));
+    Fp<P> t3 = fp_add<P>(cg, fp_mul<P>(load_fr<P>(q.s3 + o), q.beta_m));
+    Fp<P> right = fp_mul<P>(fp_mul<P>(fp_mul<P>(fp_mul<P>(t1, t2), t3), zw), q.alpha_r4);
+    Fp<P> one_raw = fp_zero<P>();
+    one_raw.v[0] = 1;  // the integer 1 (vectors are canonical, not Montgomery)
+    Fp<P> bound = fp_mul<P>(fp_mul<P>(fp_sub<P>(z, one_raw), load_fr<P>(q.l1 + o)), q.alpha2_r2);
+    Fp<P> total = fp_add<P>(fp_add<P>(g, fp_sub<P>(left, right)), bound);
+    store_fr<P>(out + o, fp_reduce_full<P>(fp_mul<P>(total, q.zh_inv_m[i % q.period])));
+}
+
+// Horner evaluation split over threads: thread t evaluates its chunk of `chunk` coefficients at x and weighs it
+// with x^(t chunk); a workgroup adds its 256 values in LDS and stores one partial sum (canonical).
+template <class P>
+__global__ __launch_bounds__(256) void poly_eval_kernel(uint64_t n, uint32_t chunk, const uint32_t* __restrict__ coeffs, Fp<P> x_m,
+                                                        uint32_t* __restrict__ partial) {
+    __shared__ uint32_t lds[P::N][256];
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lo = t * chunk;
+    Fp<P> acc = fp_zero<P>();
+    if (lo < n) {
+        uint64_t hi = lo + chunk < n ? lo + chunk : n;
+        for (uint64_t k = hi; k-- > lo;) acc = fp_add<P>(fp_mul<P>(acc, x_m), load_fr<P>(coeffs + k * P::W));
+        uint32_t e[2] = {(uint32_t)lo, (uint32_t)(lo >> 32)};
+        acc = fp_mul<P>(acc, fp_pow<P>(x_m, e, 2));
+    }
+#pragma unroll
+    for (int l = 0; l < P::N; ++l) lds[l][threadIdx.x] = acc.v[l];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            Fp<P> u, v;
+#pragma unroll
+            for (int l = 0; l < P::N; ++l) { u.v[l] = lds[l][threadIdx.x]; v.v[l] = lds[l][threadIdx.x + s]; }
+            u = fp_add<P>(u, v);
+#pragma unroll
+            for (int l = 0; l < P::N; ++l) lds[l][threadIdx.x] = u.v[l];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        Fp<P> u;
+#pragma unroll
+        for (int l = 0; l < P::N; ++l) u.v[l] = lds[l][0];
+        store_fr<P>(partial + (size_t)blockIdx.x * P::W, fp_reduce_full<P>(u));
+    }
+}
+
+// ---- host wrappers ------------------------------------------------------------------------------------
+
+template <class P>
+static int axpby_impl(uint64_t n, const uint64_t* a, const void* x, const uint64_t* b, const void* y, const uint64_t* c, void* out, hipStream_t st) {
+    if (n == 0) return ZK_OK;
+    if (!a || !x || !out) return fail(ZK_ERR_ARG, "axpby: null argument");
+    if ((b == nullptr) != (y == nullptr)) return fail(ZK_ERR_ARG, "axpby: b and y go together");
+    Fp<P> am = scalar_times_r<P>(a, 1), bm = b ? scalar_times_r<P>(b, 1) : fp_zero<P>(), cc = c ? scalar_in<P>(c) : fp_zero<P>();
+    hipLaunchKernelGGL(axpby_kernel<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, am, (const uint32_t*)x, bm,
+                       (const uint32_t*)y, cc, (uint32_t*)out);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+template <class P>
+static int is_zero_impl(uint64_t n, const void* x, int* is_zero, hipStream_t st) {
+    *is_zero = 1;
+    if (n == 0) return ZK_OK;
+    int* dflag = nullptr;
+    ZK_HIP(hipMalloc(&dflag, sizeof(int)));
+    int flag = 0, rc = ZK_OK;
+    do {
+        if (hipMemsetAsync(dflag, 0, sizeof(int), st) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemsetAsync failed"); break; }
+        uint64_t nv = n * (P::W / 4);
+        hipLaunchKernelGGL(is_zero_kernel<P>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, nv, (const uint4*)x, dflag);
+        if (hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = fail(ZK_ERR_HIP, "is_zero: copy back failed"); break; }
+    } while (0);
+    (void)hipFree(dflag);
+    *is_zero = flag ? 0 : 1;
+    return rc;
+}
+
+template <class P>
+static int perm_terms_impl(uint64_t n, const void* const* w, const void* const* l, const uint64_t* beta, const uint64_t* gamma, void* out, hipStream_t st) {
+    if (n == 0) return ZK_OK;
+    hipLaunchKernelGGL(perm_terms_kernel<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (const uint32_t*)w[0], (const uint32_t*)w[1],
+                       (const uint32_t*)w[2], (const uint32_t*)l[0], (const uint32_t*)l[1], (const uint32_t*)l[2], scalar_times_r<P>(beta, 1),
+                       scalar_in<P>(gamma), (uint32_t*)out);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+template <class P>
+static int quotient_impl(uint64_t m, uint64_t n, const void* const* cols, const uint64_t* zh_inv, const uint64_t* beta, const uint64_t* gamma,
+                         const uint64_t* alpha, void* out, hipStream_t st) {
+    if (n == 0 || m % n != 0 || m / n > QUOT_MAX_PERIOD || m / n < 2) return fail(ZK_ERR_ARG, "quotient: coset size must be 2..16 times n");
+    QuotientArgs<P> q;
+    const uint32_t** dst[15] = {&q.a, &q.b, &q.c, &q.z, &q.pi, &q.ql, &q.qr, &q.qo, &q.qm, &q.qc, &q.s1, &q.s2, &q.s3, &q.x, &q.l1};
+    for (int k = 0; k < 15; ++k) {
+        if (!cols[k]) return fail(ZK_ERR_ARG, "quotient: null column");
+        *dst[k] = (const uint32_t*)cols[k];
+    }
+    q.period = (uint32_t)(m / n);
+    q.beta_m = scalar_times_r<P>(beta, 1);
+    q.gamma = scalar_in<P>(gamma);
+    q.alpha_r4 = scalar_times_r<P>(alpha, 4);
+    Fp<P> am = fp_from_canonical<P>(reinterpret_cast<const uint32_t*>(alpha));
+    Fp<P> a2 = fp_mul<P>(am, am);  // alpha^2 R
+    q.alpha2_r2 = fp_reduce_full<P>(fp_mul<P>(a2, fp_const<P>(P::R2)));
+    for (uint32_t k = 0; k < QUOT_MAX_PERIOD; ++k)
+        q.zh_inv_m[k] = k < q.period ? scalar_times_r<P>(zh_inv + 4 * k, 1) : fp_zero<P>();
+    hipLaunchKernelGGL(quotient_kernel<P>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, q, (uint32_t*)out);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+template <class P>
+static int poly_eval_impl_dev(uint64_t n, const void* coeffs, const uint64_t* x, uint64_t* out, hipStream_t st) {
+    uint32_t* o = reinterpret_cast<uint32_t*>(out);
+    for (int k = 0; k < P::W; ++k) o[k] = 0;
+    if (n == 0) return ZK_OK;
+    const uint32_t chunk = 32;
+    uint64_t threads = (n + chunk - 1) / chunk;
+    unsigned blocks = (unsigned)((threads + 255) / 256);
+    uint32_t* dpart = nullptr;
+    ZK_HIP(hipMalloc(&dpart, (size_t)blocks * P::W * 4));
+    std::vector<uint32_t> part((size_t)blocks * P::W);
+    int rc = ZK_OK;
+    hipLaunchKernelGGL(poly_eval_kernel<P>, dim3(blocks), dim3(256), 0, st, n, chunk, (const uint32_t*)coeffs,
+                       fp_from_canonical<P>(reinterpret_cast<const uint32_t*>(x)), dpart);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(part.data(), dpart, part.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        rc = fail(ZK_ERR_HIP, "poly_eval: kernel or copy back failed");
+    (void)hipFree(dpart);
+    if (rc) return rc;
+    Fp<P> acc = fp_zero<P>();
+    for (unsigned b = 0; b < blocks; ++b) acc = fp_add<P>(acc, fp_unpack<P>(part.data() + (size_t)b * P::W));
+    fp_pack<P>(o, fp_reduce_full<P>(acc));
+    return ZK_OK;
+}
+
+}  // namespace zkmi
+
+using namespace zkmi;
+
+extern "C" {
+
+int zk_vec_axpby_dev(int curve, uint64_t n, const uint64_t* a, const void* d_x, const uint64_t* b, const void* d_y, const uint64_t* c,
+                     void* d_out, void* stream) {
+#define CALL(P) return axpby_impl<P>(n, a, d_x, b, d_y, c, d_out, (hipStream_t)stream)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_vec_is_zero_dev(int curve, uint64_t n, const void* d_x, int* is_zero, void* stream) {
+#define CALL(P) return is_zero_impl<P>(n, d_x, is_zero, (hipStream_t)stream)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_poly_eval_dev(int curve, uint64_t n, const void* d_coeffs, const uint64_t* x, uint64_t* out, void* stream) {
+#define CALL(P) return poly_eval_impl_dev<P>(n, d_coeffs, x, out, (hipStream_t)stream)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_plonk_perm_terms_dev(int curve, uint64_t n, const void* const* d_wires, const void* const* d_labels, const uint64_t* beta,
+                            const uint64_t* gamma, void* d_out, void* stream) {
+#define CALL(P) return perm_terms_impl<P>(n, d_wires, d_labels, beta, gamma, d_out, (hipStream_t)stream)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_plonk_quotient_dev(int curve, uint64_t m, uint64_t n, const void* const* d_cols, const uint64_t* zh_inv, const uint64_t* beta,
+                          const uint64_t* gamma, const uint64_t* alpha, void* d_out, void* stream) {
+#define CALL(P) return quotient_impl<P>(m, n, d_cols, zh_inv, beta, gamma, alpha, d_out, (hipStream_t)stream)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+}  // extern "C"

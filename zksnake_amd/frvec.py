@@ -5,12 +5,37 @@ host O(n) recurrences (zk_fr_poly_eval / _div_linear / _grand_product / _scale_a
 appear only for single field elements (challenges, evaluations), never per coefficient.
 """
 
+import ctypes
+
 import numpy as np
 
 from . import _native as N
 from .constant import BLS12_381_SCALAR_FIELD, BN254_SCALAR_FIELD
+from .device import DeviceBuffer
 
 _CID = {BN254_SCALAR_FIELD: N.CURVE_BN254, BLS12_381_SCALAR_FIELD: N.CURVE_BLS12_381}
+
+
+class DevVec:
+    """n canonical Fr elements in HBM"""
+
+    def __init__(self, n, zero=True):
+        self.n = n
+        self.buf = DeviceBuffer(32 * max(n, 1))
+        if zero:
+            self.buf.zero()
+
+    def ptr(self, offset=0):
+        assert 0 <= offset <= self.n
+        return self.buf.ptr + 32 * offset
+
+    def upload(self, limbs, offset=0):
+        assert offset + limbs.shape[0] <= self.n
+        self.buf.upload(limbs, 32 * offset)
+
+    def download(self, count=None, offset=0):
+        count = self.n - offset if count is None else count
+        return self.buf.download((count, 4), np.uint64, 32 * offset)
 
 
 class FrOps:
@@ -118,3 +143,56 @@ class FrOps:
         if x.shape[0]:
             N.check(lib.zk_fr_scale_add(self.cid, x.shape[0], N.u64p(acc), N.u64p(np.ascontiguousarray(x)), N.u64p(self.one(s))))
         return acc
+
+    # -- device-resident forms (vectors stay in HBM between calls; only scalars and a few coefficients move) --
+    def d_from(self, limbs, size=None):
+        """host limbs -> DevVec of `size` elements (zero padded)"""
+        limbs = np.ascontiguousarray(limbs, dtype=np.uint64).reshape(-1, 4)
+        vec = DevVec(size or limbs.shape[0], zero=bool(size and size > limbs.shape[0]))
+        if limbs.shape[0]:
+            vec.upload(limbs)
+        return vec
+
+    def d_ntt(self, vec, size, inverse=False):
+        """in place on the first `size` (a power of two) elements"""
+        assert size & (size - 1) == 0 and size <= vec.n
+        N.check(N.load().zk_ntt_dev(self.cid, int(inverse), size.bit_length() - 1, vec.ptr(), None))
+
+    def d_op(self, op, n, a_ptr, b_ptr, out_ptr):
+        N.check(N.load().zk_vec_op_dev(self.cid, op, n, a_ptr, b_ptr, out_ptr, None))
+
+    def d_mul(self, n, a_ptr, b_ptr, out_ptr):
+        self.d_op(0, n, a_ptr, b_ptr, out_ptr)
+
+    def d_add(self, n, a_ptr, b_ptr, out_ptr):
+        self.d_op(1, n, a_ptr, b_ptr, out_ptr)
+
+    def d_axpy(self, n, acc_ptr, s, x_ptr):
+        """acc[:n] += s * x[:n]"""
+        N.check(N.load().zk_vec_axpby_dev(self.cid, n, N.u64p(self.one(1)), acc_ptr, N.u64p(self.one(s)), x_ptr, None, acc_ptr, None))
+
+    def d_is_zero(self, n, ptr):
+        flag = ctypes.c_int(0)
+        N.check(N.load().zk_vec_is_zero_dev(self.cid, n, ptr, ctypes.byref(flag), None))
+        return bool(flag.value)
+
+    def d_eval(self, n, ptr, x):
+        out = np.zeros(4, dtype=np.uint64)
+        N.check(N.load().zk_poly_eval_dev(self.cid, n, ptr, N.u64p(self.one(x)), N.u64p(out), None))
+        return int.from_bytes(out.tobytes(), "little")
+
+    def d_add_at(self, vec, i, value):
+        """vec[i] += value (mod r): one 32-byte round trip"""
+        cur = vec.download(1, i)
+        self.add_at(cur, 0, value)
+        vec.upload(cur, i)
+
+    def d_perm_terms(self, n, wires, labels, beta, gamma, out_ptr):
+        arr = ctypes.c_void_p * 3
+        N.check(N.load().zk_plonk_perm_terms_dev(self.cid, n, arr(*wires), arr(*labels), N.u64p(self.one(beta)), N.u64p(self.one(gamma)),
+                                                  out_ptr, None))
+
+    def d_quotient(self, m, n, cols, zh_inv, beta, gamma, alpha, out_ptr):
+        arr = ctypes.c_void_p * 15
+        N.check(N.load().zk_plonk_quotient_dev(self.cid, m, n, arr(*cols), N.u64p(np.ascontiguousarray(zh_inv)), N.u64p(self.one(beta)),
+                                                N.u64p(self.one(gamma)), N.u64p(self.one(alpha)), out_ptr, None))

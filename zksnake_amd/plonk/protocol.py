@@ -16,8 +16,10 @@ How the prover is organised here (the reference multiplies coefficient-form poly
     (the reference's own `coset_fft` offsets by the domain generator, which maps H_4n onto itself, so the coset here is
     formed explicitly: coefficients are scaled by g^i, g the field's multiplicative generator, before a plain NTT);
   * z(omega X) on the coset is z's evaluation vector rotated by 4n / n = four places; no second transform;
-  * the O(n) sequential pieces (grand product, Horner evaluations, division by X - zeta, the linearisation's
-    multiply-adds) are host C++ (zk_fr_*), never per-coefficient Python.
+  * vectors stay in HBM for the whole proof (the witness goes up once; a few blinded coefficients, the grand-product
+    terms and the two opening numerators come down); evaluations at zeta are a device reduction, the linearisation is
+    a chain of device multiply-adds, the commitments read their scalars in place;
+  * what is still sequential on the host (C++, zk_fr_*): the grand product and the two divisions by X - zeta.
 """
 
 import numpy as np
@@ -25,7 +27,7 @@ import numpy as np
 from .. import _native as N
 from ..arithmetization.plonkish import Plonkish
 from ..ecc import EllipticCurve, PointArray
-from ..frvec import FrOps
+from ..frvec import DevVec, FrOps
 from ..transcript import FiatShamirTranscript
 from ..utils import get_random_int
 from .serialization import SELECTORS, Proof, ProvingKey, VerifyingKey
@@ -50,14 +52,31 @@ class Plonk:
         self.last_timings = {}
 
     # ------------------------------------------------------------------------------------------
-    def _commit(self, coeffs):
-        """<tau_g1[:len], coeffs> on the resident plan of the proving key's tau_g1"""
-        pk = self.proving_key
+    def _tau_plan(self):
+        """the resident fixed-base MSM plan over the proving key's tau_g1 (all commitments of a proof use it)"""
+        pk, cid = self.proving_key, self.E.curve.curve_id
         if not isinstance(pk.tau_g1, PointArray):
             from .._algebra import _points_to_limbs
-            pk.tau_g1 = PointArray(self.E.curve.curve_id, 1, _points_to_limbs(pk.tau_g1, self.E.curve.curve_id, 1))
-        assert len(coeffs) <= len(pk.tau_g1), "Constraints are too big for the given g1_tau"
-        return self.E.multiexp(pk.tau_g1, np.ascontiguousarray(coeffs))
+            pk.tau_g1 = PointArray(cid, 1, _points_to_limbs(pk.tau_g1, cid, 1))
+        return pk.tau_g1.plan(precompute=True)
+
+    def _run_plan(self, count, scalars_ptr, on_device):
+        cid = self.E.curve.curve_id
+        assert count <= len(self.proving_key.tau_g1), "Constraints are too big for the given g1_tau"
+        out = np.zeros(N.point_limbs(cid, 1), dtype=np.uint64)
+        if count:
+            N.check(N.load().zk_msm_plan_run(self._tau_plan(), count, scalars_ptr, on_device, 0, 0, N.u64p(out), None))
+        from .._algebra import _point_class
+        return _point_class(cid, 1)._from_limbs(out)
+
+    def _commit(self, coeffs):
+        """<tau_g1[:len], coeffs> for a coefficient vector in host memory"""
+        coeffs = np.ascontiguousarray(coeffs)
+        return self._run_plan(coeffs.shape[0], coeffs.ctypes.data, 0)
+
+    def _commit_dev(self, vec, count, offset=0):
+        """<tau_g1[:count], vec[offset:offset+count]> with the scalars read in place from HBM"""
+        return self._run_plan(count, vec.ptr(offset), 1)
 
     def setup(self, g1_tau=None, g2_tau=None):
         """universal setup (or reuse of given powers of tau) + circuit preprocessing (protocol.py:39-155)"""
@@ -95,61 +114,65 @@ class Plonk:
         self.verifying_key = VerifyingKey(n, self.G2_tau, pk.tau_selector_poly, pk.tau_permutation_poly, self.E.name)
 
     # ------------------------------------------------------------------------------------------
-    def _key_columns(self):
-        """per-key vectors the prover reuses across proofs: the n-domain labels and the 4n-coset evaluations"""
-        pk, V, n, r = self.proving_key, self._ops, self.proving_key.n, self.order
-        cache = pk._cache
-        if "coset" not in cache:
-            roots = V.ntt(V.limbs([0, 1]) if n > 1 else V.limbs([1]), n)
-            id2 = V.add(roots, roots)
-            cache["id_evals"] = [roots, id2, V.add(id2, roots)]
-            if "sigma_evals" not in cache:  # key came from bytes
-                cache["sigma_evals"] = [V.ntt(p, n) for p in pk._permutation]
-            m = self._quotient_domain()
-            g = COSET_SHIFT[V.cid]
-            assert pow(g, m, r) != 1
-            cache["shift"] = (V.powers(g, m), V.powers(pow(g, -1, r), m))
-            x = self._to_coset(V.limbs([0, 1]))                        # the coset points g * omega_4n^i
-            # 1 / (x^n - 1) on the coset has period m / n
-            xn = [pow(V.int_at(x, i), n, r) for i in range(m // n)]
-            zh_inv = np.tile(V.limbs([pow(v - 1, -1, r) for v in xn]), (n, 1))
-            cache["coset"] = {
-                "x": x, "zh_inv": zh_inv, "l1": self._to_coset(V.const(pow(n, -1, r), n)),
-                "q": {k: self._to_coset(pk._selector[k]) for k in SELECTORS},
-                "sigma": [self._to_coset(p) for p in pk._permutation],
-            }
-        return cache
-
     def _quotient_domain(self):
-        """size of the coset the quotient (degree 3n + 5) is interpolated on: 4n, or 8n for the tiniest circuits"""
+        """size of the coset the quotient (degree 3n + 5) is interpolated on: 4n, or 8n / 16n for the tiniest circuits"""
         n = self.proving_key.n
         return max(4 * n, 1 << (3 * n + 5).bit_length())
 
-    def _to_coset(self, coeffs):
-        """evaluations of a coefficient vector on g * H_m"""
-        V, m = self._ops, self._quotient_domain()
-        fwd = self.proving_key._cache["shift"][0]
-        k = coeffs.shape[0]
-        return V.ntt(V.mul(np.ascontiguousarray(coeffs), np.ascontiguousarray(fwd[:k])), m)
+    def _key_columns(self):
+        """per-key vectors the prover reuses across proofs, resident in HBM: coefficient vectors, the n-domain
+        columns and labels, and the coset evaluations the quotient kernel reads"""
+        pk, V, n, r = self.proving_key, self._ops, self.proving_key.n, self.order
+        cache = pk._cache
+        if "dev" not in cache:
+            m = self._quotient_domain()
+            g = COSET_SHIFT[V.cid]
+            assert pow(g, m, r) != 1
+            roots = V.ntt(V.limbs([0, 1]) if n > 1 else V.limbs([1]), n)
+            id2 = V.add(roots, roots)
+            sigma_evals = cache.get("sigma_evals")
+            if sigma_evals is None:  # key came from bytes
+                sigma_evals = [V.ntt(p, n) for p in pk._permutation]
+            dev = {
+                "m": m, "omega": V.int_at(roots, 1) if n > 1 else 1,
+                "shift": (V.d_from(V.powers(g, m)), V.d_from(V.powers(pow(g, -1, r), m))),
+                "id_labels": [V.d_from(v) for v in (roots, id2, V.add(id2, roots))],
+                "sigma_labels": [V.d_from(np.ascontiguousarray(v)) for v in sigma_evals],
+                "q_coeffs": {k: V.d_from(pk._selector[k], n) for k in SELECTORS},
+                "sigma_coeffs": [V.d_from(p, n) for p in pk._permutation],
+                "q_columns": {k: V.d_from(self._column(k)) for k in SELECTORS},
+            }
+            cache["dev"] = dev
+            x = self._to_coset(V.d_from(V.limbs([0, 1])), 2)                # the coset points g * omega_m^i
+            xs = x.download(m // n)
+            dev["zh_inv"] = V.limbs([pow(pow(V.int_at(xs, i), n, r) - 1, -1, r) for i in range(m // n)])  # period m / n
+            dev["x"] = x
+            dev["l1"] = self._to_coset(V.d_from(V.const(pow(n, -1, r), n)), n)
+            dev["q"] = {k: self._to_coset(dev["q_coeffs"][k], n) for k in SELECTORS}
+            dev["sigma"] = [self._to_coset(p, n) for p in dev["sigma_coeffs"]]
+        return cache["dev"]
 
-    def _from_coset(self, evals):
-        V, m = self._ops, self._quotient_domain()
-        return V.mul(V.ntt(evals, m, inverse=True), self.proving_key._cache["shift"][1])
+    def _to_coset(self, coeffs, count):
+        """evaluations on g * H_m of the polynomial held in the first `count` entries of a device vector"""
+        V, dev = self._ops, self.proving_key._cache["dev"]
+        out = DevVec(dev["m"])
+        V.d_mul(count, coeffs.ptr(), dev["shift"][0].ptr(), out.ptr())
+        V.d_ntt(out, dev["m"])
+        return out
 
-    def _blind(self, coeffs, n, scalars):
-        """coeffs += (s0 + s1 X + ..)(X^n - 1), in place"""
+    def _blind(self, vec, n, scalars):
+        """vec += (s0 + s1 X + ..)(X^n - 1) on a device coefficient vector"""
         for i, s in enumerate(scalars):
-            self._ops.add_at(coeffs, i, -s)
-            self._ops.add_at(coeffs, n + i, s)
+            self._ops.d_add_at(vec, i, -s)
+            self._ops.d_add_at(vec, n + i, s)
 
     def prove(self, public_witness: dict, private_witness) -> Proof:
         """public_witness: {row: value}; private_witness: flat [a0, b0, c0, a1, ...] as ints or a (3k, 4) limb array."""
         assert self.proving_key, "ProvingKey has not been generated"
         pk, V, r = self.proving_key, self._ops, self.order
         n = pk.n
-        m = self._quotient_domain()
-        cache = self._key_columns()
-        cos = cache["coset"]
+        dev = self._key_columns()
+        m = dev["m"]
         blind = list(self._blinding) if self._blinding is not None else [get_random_int(r - 1) for _ in range(11)]
 
         wit = V.limbs(private_witness)
@@ -171,113 +194,116 @@ class Plonk:
         for _, v in public_witness.items():
             transcript.append(v)
 
+        # the witness goes up once: as n-domain columns (gate check, grand product) and as the start of the
+        # coefficient vectors (m entries, so the same buffers later feed the coset transforms)
+        col_d = [V.d_from(c) for c in cols]
+        pi_d = V.d_from(pi_evals)
+        qc = dev["q_columns"]
+        # the gate identity has to hold on H itself, else the "quotient" is not a polynomial (the reference asserts a
+        # zero remainder, protocol.py:347)
+        g1, g2 = DevVec(n, zero=False), DevVec(n, zero=False)
+        V.d_mul(n, col_d[0].ptr(), qc["L"].ptr(), g1.ptr())
+        for wire, sel in ((col_d[1], qc["R"]), (col_d[2], qc["O"])):
+            V.d_mul(n, wire.ptr(), sel.ptr(), g2.ptr())
+            V.d_add(n, g1.ptr(), g2.ptr(), g1.ptr())
+        V.d_mul(n, col_d[0].ptr(), col_d[1].ptr(), g2.ptr())
+        V.d_mul(n, g2.ptr(), qc["M"].ptr(), g2.ptr())
+        V.d_add(n, g1.ptr(), g2.ptr(), g1.ptr())
+        V.d_add(n, g1.ptr(), qc["C"].ptr(), g1.ptr())
+        V.d_add(n, g1.ptr(), pi_d.ptr(), g1.ptr())
+        assert V.d_is_zero(n, g1.ptr()), "gate constraints are not satisfied"
+
         # -- round 1: blinded wire polynomials and their commitments ---------------------------------
         wires = []
         for j in range(3):
-            coeffs = V.zeros(n + 2)
-            coeffs[:n] = V.ntt(cols[j], n, inverse=True)
-            self._blind(coeffs, n, blind[2 * j:2 * j + 2])
-            wires.append(coeffs)
-        pi_coeffs = V.ntt(pi_evals, n, inverse=True)
-        tau_w = [self._commit(w) for w in wires]
+            w = V.d_from(cols[j], m)
+            V.d_ntt(w, n, inverse=True)
+            self._blind(w, n, blind[2 * j:2 * j + 2])
+            wires.append(w)
+        pi_c = V.d_from(pi_evals, m)
+        V.d_ntt(pi_c, n, inverse=True)
+        tau_w = [self._commit_dev(w, n + 2) for w in wires]
         for point in tau_w:
             transcript.append(point)
 
         # -- round 2: permutation grand product z --------------------------------------------------
         beta = transcript.get_challenge_scalar()
         gamma = transcript.get_challenge_scalar()
-        beta_n, gamma_n = V.const(beta, n), V.const(gamma, n)
-
-        def column_product(labels):
-            acc = None
-            for col, lab in zip(cols, labels):
-                term = V.add(V.add(col, V.mul(beta_n, np.ascontiguousarray(lab))), gamma_n)
-                acc = term if acc is None else V.mul(acc, term)
-            return acc
-
-        acc = V.grand_product(column_product(cache["id_evals"]), column_product(cache["sigma_evals"]))
+        wire_ptrs = [c.ptr() for c in col_d]
+        V.d_perm_terms(n, wire_ptrs, [v.ptr() for v in dev["id_labels"]], beta, gamma, g1.ptr())
+        V.d_perm_terms(n, wire_ptrs, [v.ptr() for v in dev["sigma_labels"]], beta, gamma, g2.ptr())
+        acc = V.grand_product(g1.download(), g2.download())
         assert V.int_at(acc, n) == 1, "Copy constraints are not satisfied"
-        z = V.zeros(n + 3)
-        z[:n] = V.ntt(np.ascontiguousarray(acc[:n]), n, inverse=True)
+        z = V.d_from(acc[:n], m)
+        V.d_ntt(z, n, inverse=True)
         self._blind(z, n, blind[6:9])
-        tau_z = self._commit(z)
+        tau_z = self._commit_dev(z, n + 3)
         transcript.append(tau_z)
 
-        # -- round 3: quotient on the coset g * H_4n -----------------------------------------------
+        # -- round 3: quotient on the coset g * H_m ------------------------------------------------
         alpha = transcript.get_challenge_scalar()
-        a_e, b_e, c_e = (self._to_coset(w) for w in wires)
-        z_e = self._to_coset(z)
-        zw_e = np.ascontiguousarray(np.roll(z_e, -(m // n), axis=0))
-        pi_e = self._to_coset(pi_coeffs)
-        q = cos["q"]
-        # the gate identity also has to hold on H itself, else the "quotient" is not a polynomial (the reference
-        # asserts a zero remainder, protocol.py:347); checked on the n-domain where it costs 1/4 of a coset pass
-        gate_h = V.add(V.add(V.add(V.mul(cols[0], V.limbs(self._column("L"))), V.mul(cols[1], V.limbs(self._column("R")))),
-                             V.add(V.mul(cols[2], V.limbs(self._column("O"))), V.mul(V.mul(cols[0], cols[1]), V.limbs(self._column("M"))))),
-                       V.add(V.limbs(self._column("C")), pi_evals))
-        assert not gate_h.any(), "gate constraints are not satisfied"
-
-        gate = V.add(V.add(V.add(V.mul(a_e, q["L"]), V.mul(b_e, q["R"])), V.add(V.mul(c_e, q["O"]), V.mul(V.mul(a_e, b_e), q["M"]))),
-                     V.add(q["C"], pi_e))
-        beta_m, gamma_m = V.const(beta, m), V.const(gamma, m)
-        bx = V.mul(beta_m, cos["x"])
-        bx2 = V.add(bx, bx)
-        ag, bg, cg = V.add(a_e, gamma_m), V.add(b_e, gamma_m), V.add(c_e, gamma_m)
-        left = V.mul(V.mul(V.mul(V.add(ag, bx), V.add(bg, bx2)), V.add(cg, V.add(bx2, bx))), z_e)
-        s = cos["sigma"]
-        right = V.mul(V.mul(V.mul(V.add(ag, V.mul(beta_m, s[0])), V.add(bg, V.mul(beta_m, s[1]))), V.add(cg, V.mul(beta_m, s[2]))), zw_e)
-        boundary = V.mul(V.sub(z_e, V.const(1, m)), cos["l1"])
-        numer = V.add(V.add(gate, V.mul(V.const(alpha, m), V.sub(left, right))), V.mul(V.const(alpha * alpha % r, m), boundary))
-        t = self._from_coset(V.mul(numer, cos["zh_inv"]))
-        assert not t[3 * n + 6:].any(), "quotient has a remainder"
-        t_lo, t_mid, t_hi = V.zeros(n + 1), V.zeros(n + 1), V.zeros(n + 6)
-        t_lo[:n], t_mid[:n], t_hi[:] = t[:n], t[n:2 * n], t[2 * n:3 * n + 6]
-        V.add_at(t_lo, n, blind[9])
-        V.add_at(t_mid, 0, -blind[9])
-        V.add_at(t_mid, n, blind[10])
-        V.add_at(t_hi, 0, -blind[10])
-        tau_t = [self._commit(p) for p in (t_lo, t_mid, t_hi)]
+        a_e, b_e, c_e = (self._to_coset(w, n + 2) for w in wires)
+        z_e = self._to_coset(z, n + 3)
+        pi_e = self._to_coset(pi_c, n)
+        q, sg = dev["q"], dev["sigma"]
+        t = DevVec(m, zero=False)
+        V.d_quotient(m, n, [a_e.ptr(), b_e.ptr(), c_e.ptr(), z_e.ptr(), pi_e.ptr(), q["L"].ptr(), q["R"].ptr(), q["O"].ptr(), q["M"].ptr(),
+                            q["C"].ptr(), sg[0].ptr(), sg[1].ptr(), sg[2].ptr(), dev["x"].ptr(), dev["l1"].ptr()],
+                     dev["zh_inv"], beta, gamma, alpha, t.ptr())
+        V.d_ntt(t, m, inverse=True)
+        V.d_mul(m, t.ptr(), dev["shift"][1].ptr(), t.ptr())
+        assert m == 3 * n + 6 or V.d_is_zero(m - (3 * n + 6), t.ptr(3 * n + 6)), "quotient has a remainder"
+        # T = t_lo + X^n t_mid + X^2n t_hi with t_lo += b9 X^n, t_mid += -b9 + b10 X^n, t_hi += -b10: the blinding terms
+        # are added on the group side (tau_g1[0] = G, tau_g1[n] = tau^n G)
+        G, Gn = pk.tau_g1[0], pk.tau_g1[n]
+        tau_t = [self._commit_dev(t, n) + Gn * blind[9],
+                 self._commit_dev(t, n, n) + G * ((-blind[9]) % r) + Gn * blind[10],
+                 self._commit_dev(t, n + 6, 2 * n) + G * ((-blind[10]) % r)]
         for point in tau_t:
             transcript.append(point)
 
         # -- round 4: openings at zeta and the linearisation polynomial ----------------------------
         zeta = transcript.get_challenge_scalar()
-        omega = V.int_at(cache["id_evals"][0], 1) if n > 1 else 1
-        za, zb, zc = (V.eval(w, zeta) for w in wires)
-        zs1, zs2 = V.eval(pk._permutation[0], zeta), V.eval(pk._permutation[1], zeta)
-        zzw = V.eval(z, zeta * omega % r)
+        omega = dev["omega"]
+        sc = dev["sigma_coeffs"]
+        za, zb, zc = (V.d_eval(n + 2, w.ptr(), zeta) for w in wires)
+        zs1, zs2 = V.d_eval(n, sc[0].ptr(), zeta), V.d_eval(n, sc[1].ptr(), zeta)
+        zzw = V.d_eval(n + 3, z.ptr(), zeta * omega % r)
+        pi_zeta = V.d_eval(n, pi_c.ptr(), zeta)
         zeta_n = pow(zeta, n, r)
         zh_zeta = (zeta_n - 1) % r
         l1_zeta = zh_zeta * pow(n * (zeta - 1) % r, -1, r) % r
-        pi_zeta = V.eval(pi_coeffs, zeta)
         f1 = (za + beta * zeta + gamma) * (zb + beta * K1 * zeta + gamma) * (zc + beta * K2 * zeta + gamma) % r
         f2 = (za + beta * zs1 + gamma) * (zb + beta * zs2 + gamma) * zzw % r
         a2l1 = alpha * alpha * l1_zeta % r
 
-        lin = V.zeros(n + 6)
+        lin = DevVec(n + 6)
         for k, weight in zip(SELECTORS, (za, zb, zc, za * zb % r, 1)):
-            V.scale_add(lin, pk._selector[k], weight)
-        V.scale_add(lin, z, (alpha * f1 + a2l1) % r)
-        V.scale_add(lin, pk._permutation[2], -alpha * f2 * beta % r)
-        for part, weight in ((t_lo, 1), (t_mid, zeta_n), (t_hi, zeta_n * zeta_n % r)):
-            V.scale_add(lin, part, -zh_zeta * weight % r)
-        V.add_at(lin, 0, pi_zeta - alpha * f2 * (zc + gamma) - a2l1)
+            V.d_axpy(n, lin.ptr(), weight, dev["q_coeffs"][k].ptr())
+        V.d_axpy(n + 3, lin.ptr(), (alpha * f1 + a2l1) % r, z.ptr())
+        V.d_axpy(n, lin.ptr(), -alpha * f2 * beta % r, sc[2].ptr())
+        w_mid, w_hi = zh_zeta * zeta_n % r, zh_zeta * zeta_n * zeta_n % r
+        V.d_axpy(n, lin.ptr(), -zh_zeta % r, t.ptr())
+        V.d_axpy(n, lin.ptr(), -w_mid % r, t.ptr(n))
+        V.d_axpy(n + 6, lin.ptr(), -w_hi % r, t.ptr(2 * n))
         for value in (za, zb, zc, zs1, zs2, zzw):
             transcript.append(value)
 
         # -- round 5: opening proofs --------------------------------------------------------------------
         v = transcript.get_challenge_scalar()
         vk_pow, shift = 1, 0
-        for poly, value in ((wires[0], za), (wires[1], zb), (wires[2], zc), (pk._permutation[0], zs1), (pk._permutation[1], zs2)):
+        for poly, count, value in ((wires[0], n + 2, za), (wires[1], n + 2, zb), (wires[2], n + 2, zc), (sc[0], n, zs1), (sc[1], n, zs2)):
             vk_pow = vk_pow * v % r
-            V.scale_add(lin, poly, vk_pow)
+            V.d_axpy(count, lin.ptr(), vk_pow, poly.ptr())
             shift += vk_pow * value
-        V.add_at(lin, 0, -shift)
-        w_zeta, rem = V.div_linear(lin, zeta)
+        # constant and X^n corrections: PI(zeta), the sigma_3 / L1 constants, the quotient blinding, the opening values
+        V.d_add_at(lin, 0, pi_zeta - alpha * f2 * (zc + gamma) - a2l1 + w_mid * blind[9] + w_hi * blind[10] - shift)
+        V.d_add_at(lin, n, -zh_zeta * blind[9] - w_mid * blind[10])
+        w_zeta, rem = V.div_linear(lin.download(), zeta)
         assert rem == 0
-        z_shift = z.copy()
-        V.add_at(z_shift, 0, -zzw)
-        w_zeta_omega, rem = V.div_linear(z_shift, zeta * omega % r)
+        z_host = z.download(n + 3)
+        V.add_at(z_host, 0, -zzw)
+        w_zeta_omega, rem = V.div_linear(z_host, zeta * omega % r)
         assert rem == 0
         tau_w_zeta, tau_w_zeta_omega = self._commit(w_zeta), self._commit(w_zeta_omega)
 
@@ -286,14 +312,9 @@ class Plonk:
 
     def _column(self, k):
         """selector column k on the n-domain (from the circuit when present, else from the key's polynomial)"""
-        cache = self.proving_key._cache
-        key = "col_" + k
-        if key not in cache:
-            if self.constraints is not None and self.constraints.qL is not None:
-                cache[key] = self._ops.limbs(getattr(self.constraints, "q" + k))
-            else:
-                cache[key] = self._ops.ntt(self.proving_key._selector[k], self.proving_key.n)
-        return cache[key]
+        if self.constraints is not None and self.constraints.qL is not None:
+            return self._ops.limbs(getattr(self.constraints, "q" + k))
+        return self._ops.ntt(self.proving_key._selector[k], self.proving_key.n)
 
     # ------------------------------------------------------------------------------------------
     def _recompute_challenges(self, proof: Proof, public_input: dict):
