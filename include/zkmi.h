@@ -173,6 +173,12 @@ int zk_poly_eval_dev(int curve, uint64_t n, const void* d_coeffs, const uint64_t
  * (protocol.py:270-292), labels = the identity or the sigma columns on the n-domain */
 int zk_plonk_perm_terms_dev(int curve, uint64_t n, const void* const* d_wires, const void* const* d_labels, const uint64_t* beta,
                             const uint64_t* gamma, void* d_out, void* stream);
+/* d_out (n + 1 elements): out[0] = 1, out[i+1] = out[i] * num[i] / den[i] -- the batch_modinv + accumulator loop of
+ * protocol.py:296-307 as two product scans, one inversion and one element-wise pass.  ZK_ERR_ARG on a zero denominator. */
+int zk_plonk_grand_product_dev(int curve, uint64_t n, const void* d_num, const void* d_den, void* d_out, void* stream);
+/* coeffs (n) = q (n - 1 elements, device) * (X - root) + rem (host): Polynomial.__truediv__ by a linear factor
+ * (src/bn254/polynomial.rs:404-438) as a geometric rescale, a suffix-sum scan and a rescale back; d_q may not alias d_coeffs */
+int zk_poly_div_linear_dev(int curve, uint64_t n, const void* d_coeffs, const uint64_t* root, void* d_q, uint64_t* rem, void* stream);
 /* Quotient evaluations on a coset of size m = k*n (2 <= k <= 16) (protocol.py:309-347 evaluated pointwise):
  * out = [gate + alpha*(prod(w_j + beta*k_j*x + gamma)*z - prod(w_j + beta*sigma_j + gamma)*z(omega x)) + alpha^2*(z - 1)*L1] / (x^n - 1)
  * d_cols = 15 vectors of m elements: a, b, c, z, PI, qL, qR, qO, qM, qC, sigma1, sigma2, sigma3, x (the coset points), L1;

@@ -99,3 +99,41 @@ def test_unsatisfied_witnesses_are_rejected(gpu):
         plonk.prove(wrong_pub, priv)
     with pytest.raises(AssertionError, match="ProvingKey"):
         Plonk(pl, "BN254").prove(pub, priv)
+
+
+@pytest.mark.parametrize("curve", ["BN254", "BLS12_381"])
+@pytest.mark.parametrize("n", [1, 5, 16, 1000, 40000])
+def test_device_scans_against_host_helpers(gpu, curve, n):
+    """zk_plonk_grand_product_dev / zk_poly_div_linear_dev / zk_poly_eval_dev / zk_vec_axpby_dev against the sequential
+    host recurrences (zk_fr_*) and, for small n, Python integers"""
+    import numpy as np
+    from zksnake_amd import workloads as W
+    from zksnake_amd.frvec import DevVec, FrOps
+    cv = pyref.curve_by_name(curve)
+    V = FrOps(cv.r)
+    ints = W.field_stream(0xABC0 + n, 3 * n + 2, cv.r)[1]
+    num, den, root, x = V.limbs(ints[:n]), V.limbs([v or 1 for v in ints[n:2 * n]]), ints[-1], ints[-2]
+    d_num, d_den, out = V.d_from(num), V.d_from(den), DevVec(n + 1, zero=False)
+    V.d_grand_product(n, d_num.ptr(), d_den.ptr(), out.ptr())
+    assert (out.download() == V.grand_product(num, den)).all()
+    q = DevVec(max(n - 1, 1))
+    rem = V.d_div_linear(n, d_num.ptr(), root, q.ptr())
+    hq, hrem = V.div_linear(num, root)
+    assert rem == hrem == V.eval(num, root) == V.d_eval(n, d_num.ptr(), root)
+    assert (q.download(n - 1) == hq).all()
+    assert V.d_div_linear(n, d_num.ptr(), 0, q.ptr()) == ints[0] and (q.download(n - 1) == num[1:]).all()
+    V.d_axpy(n, d_den.ptr(), x, d_num.ptr())
+    exp = den.copy()
+    V.scale_add(exp, num, x)
+    assert (d_den.download() == exp).all()
+    if n <= 16:
+        acc, want = 1, [1]
+        for a, b in zip(ints[:n], [v or 1 for v in ints[n:2 * n]]):
+            acc = acc * a * pow(b, -1, cv.r) % cv.r
+            want.append(acc)
+        assert V.ints(out.download()) == want
+        assert rem == sum(c * pow(root, k, cv.r) for k, c in enumerate(ints[:n])) % cv.r
+    zero_den = den.copy()
+    zero_den[n // 2] = 0
+    with pytest.raises(Exception, match="zero denominator"):
+        V.d_grand_product(n, d_num.ptr(), V.d_from(zero_den).ptr(), out.ptr())

@@ -151,6 +151,200 @@ __global__ __launch_bounds__(256) void poly_eval_kernel(uint64_t n, uint32_t chu
     }
 }
 
+// ---- scans over Fr (grand product, division by a linear factor) ---------------------------------------------
+// Three launches: every thread folds its chunk of `chunk` consecutive elements (scan_reduce), ONE workgroup scans the
+// <= 16384 chunk totals (scan_block), every thread replays its chunk from its exclusive prefix (scan_apply).
+// `reverse` runs the same over the mirrored index, i.e. a suffix scan.  Product scans work in Montgomery form:
+// elements are converted on load and the results stay Montgomery (consumed by grand_product_finish_kernel).
+
+constexpr uint32_t SCAN_MAX_PARTIALS = 16384;  // 256 threads x 64 totals in scan_block
+
+struct ScanAdd {
+    template <class P> static __device__ __forceinline__ Fp<P> identity() { return fp_zero<P>(); }
+    template <class P> static __device__ __forceinline__ Fp<P> load(const Fp<P>& x) { return x; }
+    template <class P> static __device__ __forceinline__ Fp<P> op(const Fp<P>& a, const Fp<P>& b) { return fp_add<P>(a, b); }
+};
+struct ScanMul {
+    template <class P> static __device__ __forceinline__ Fp<P> identity() { return fp_one<P>(); }
+    template <class P> static __device__ __forceinline__ Fp<P> load(const Fp<P>& x) { return fp_mul<P>(x, fp_const<P>(P::R2)); }
+    template <class P> static __device__ __forceinline__ Fp<P> op(const Fp<P>& a, const Fp<P>& b) { return fp_mul<P>(a, b); }
+};
+
+template <class P, class Op>
+__global__ __launch_bounds__(256) void scan_reduce_kernel(uint64_t n, uint32_t chunk, int reverse, const uint32_t* __restrict__ in,
+                                                          uint32_t* __restrict__ partial) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lo = t * chunk;
+    if (lo >= n) return;
+    const uint64_t hi = lo + chunk < n ? lo + chunk : n;
+    Fp<P> acc = Op::template identity<P>();
+    for (uint64_t k = lo; k < hi; ++k) {
+        const uint64_t idx = reverse ? n - 1 - k : k;
+        acc = Op::template op<P>(acc, Op::template load<P>(load_fr<P>(in + idx * P::W)));
+    }
+    store_fr<P>(partial + t * P::W, fp_reduce_full<P>(acc));
+}
+
+// in place: partial[t] <- partial[0] o .. o partial[t-1]   (exclusive), count <= SCAN_MAX_PARTIALS, one workgroup
+template <class P, class Op>
+__global__ __launch_bounds__(256) void scan_block_kernel(uint32_t count, uint32_t* __restrict__ partial) {
+    __shared__ uint32_t lds[P::N][256];
+    const uint32_t per = (count + 255) / 256;
+    const uint32_t lo = threadIdx.x * per;
+    const uint32_t hi = lo + per < count ? lo + per : count;
+    Fp<P> acc = Op::template identity<P>();
+    for (uint32_t k = lo; k < hi; ++k) acc = Op::template op<P>(acc, load_fr<P>(partial + (size_t)k * P::W));
+#pragma unroll
+    for (int l = 0; l < P::N; ++l) lds[l][threadIdx.x] = acc.v[l];
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive scan of the 256 thread totals
+        Fp<P> other;
+        const bool take = (int)threadIdx.x >= d;
+        if (take) {
+#pragma unroll
+            for (int l = 0; l < P::N; ++l) other.v[l] = lds[l][threadIdx.x - d];
+        }
+        __syncthreads();
+        if (take) {
+            acc = Op::template op<P>(other, acc);
+#pragma unroll
+            for (int l = 0; l < P::N; ++l) lds[l][threadIdx.x] = acc.v[l];
+        }
+        __syncthreads();
+    }
+    Fp<P> run = Op::template identity<P>();
+    if (threadIdx.x > 0) {
+#pragma unroll
+        for (int l = 0; l < P::N; ++l) run.v[l] = lds[l][threadIdx.x - 1];
+    }
+    for (uint32_t k = lo; k < hi; ++k) {
+        Fp<P> e = load_fr<P>(partial + (size_t)k * P::W);
+        store_fr<P>(partial + (size_t)k * P::W, fp_reduce_full<P>(run));
+        run = Op::template op<P>(run, e);
+    }
+}
+
+// inclusive scan: out[idx(k)] = e_0 o .. o e_k over the (possibly mirrored) order
+template <class P, class Op>
+__global__ __launch_bounds__(256) void scan_apply_kernel(uint64_t n, uint32_t chunk, int reverse, const uint32_t* __restrict__ in,
+                                                         const uint32_t* __restrict__ partial, uint32_t* __restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lo = t * chunk;
+    if (lo >= n) return;
+    const uint64_t hi = lo + chunk < n ? lo + chunk : n;
+    Fp<P> acc = load_fr<P>(partial + t * P::W);
+    for (uint64_t k = lo; k < hi; ++k) {
+        const uint64_t idx = reverse ? n - 1 - k : k;
+        acc = Op::template op<P>(acc, Op::template load<P>(load_fr<P>(in + idx * P::W)));
+        store_fr<P>(out + idx * P::W, fp_reduce_full<P>(acc));
+    }
+}
+
+// out[i] = x[i] * c0 * base^i   (c0_m, base_m in Montgomery form; x and out canonical)
+template <class P>
+__global__ __launch_bounds__(256) void geom_scale_kernel(uint64_t n, uint32_t chunk, const uint32_t* __restrict__ x, Fp<P> c0_m, Fp<P> base_m,
+                                                         uint32_t* __restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lo = t * chunk;
+    if (lo >= n) return;
+    const uint64_t hi = lo + chunk < n ? lo + chunk : n;
+    uint32_t e[2] = {(uint32_t)lo, (uint32_t)(lo >> 32)};
+    Fp<P> w = fp_mul<P>(c0_m, fp_pow<P>(base_m, e, 2));  // c0 base^lo, Montgomery
+    for (uint64_t k = lo; k < hi; ++k) {
+        store_fr<P>(out + k * P::W, fp_reduce_full<P>(fp_mul<P>(load_fr<P>(x + k * P::W), w)));
+        w = fp_mul<P>(w, base_m);
+    }
+}
+
+// out[j] = PN[j] * SD[j] / Dtot  for j <= n  (PN, SD Montgomery; dinv the canonical integer 1/Dtot)
+template <class P>
+__global__ __launch_bounds__(256) void grand_product_finish_kernel(uint64_t count, const uint32_t* __restrict__ pn, const uint32_t* __restrict__ sd,
+                                                                   Fp<P> dinv, uint32_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fp<P> v = fp_mul<P>(fp_mul<P>(load_fr<P>(pn + i * P::W), load_fr<P>(sd + i * P::W)), dinv);
+    store_fr<P>(out + i * P::W, fp_reduce_full<P>(v));
+}
+
+template <class P, class Op>
+static int inclusive_scan(uint64_t n, int reverse, const uint32_t* in, uint32_t* out, uint32_t* partial, hipStream_t st) {
+    if (n == 0) return ZK_OK;
+    uint64_t chunk = (n + SCAN_MAX_PARTIALS - 1) / SCAN_MAX_PARTIALS;
+    if (chunk < 16) chunk = 16;
+    const uint64_t threads = (n + chunk - 1) / chunk;
+    const unsigned blocks = (unsigned)((threads + 255) / 256);
+    hipLaunchKernelGGL((scan_reduce_kernel<P, Op>), dim3(blocks), dim3(256), 0, st, n, (uint32_t)chunk, reverse, in, partial);
+    hipLaunchKernelGGL((scan_block_kernel<P, Op>), dim3(1), dim3(256), 0, st, (uint32_t)threads, partial);
+    hipLaunchKernelGGL((scan_apply_kernel<P, Op>), dim3(blocks), dim3(256), 0, st, n, (uint32_t)chunk, reverse, in, partial, out);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+template <class P>
+static int grand_product_dev_impl(uint64_t n, const void* num, const void* den, void* out, hipStream_t st) {
+    const size_t eb = P::W * 4;
+    uint32_t* work = nullptr;  // PN (n+1) | SD (n+1) | partials
+    ZK_HIP(hipMalloc(&work, (2 * (n + 1) + SCAN_MAX_PARTIALS) * eb));
+    uint32_t *pn = work, *sd = work + (n + 1) * P::W, *partial = work + 2 * (n + 1) * P::W;
+    int rc = ZK_OK;
+    do {
+        uint32_t one_m[P::W], dtot[P::W];
+        fp_pack<P>(one_m, fp_reduce_full<P>(fp_one<P>()));
+        if (hipMemcpyAsync(pn, one_m, eb, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(sd + n * P::W, one_m, eb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = fail(ZK_ERR_HIP, "grand product: upload failed"); break; }
+        if ((rc = inclusive_scan<P, ScanMul>(n, 0, (const uint32_t*)num, pn + P::W, partial, st))) break;
+        if ((rc = inclusive_scan<P, ScanMul>(n, 1, (const uint32_t*)den, sd, partial, st))) break;
+        if (hipMemcpyAsync(dtot, sd, eb, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            rc = fail(ZK_ERR_HIP, "grand product: copy back failed");
+            break;
+        }
+        Fp<P> d = fp_unpack<P>(dtot);  // product of all denominators, Montgomery
+        if (fp_is_zero<P>(d)) { rc = fail(ZK_ERR_ARG, "grand product: zero denominator"); break; }
+        Fp<P> one_raw = fp_zero<P>();
+        one_raw.v[0] = 1;
+        Fp<P> dinv = fp_reduce_full<P>(fp_mul<P>(fp_inv<P>(d), one_raw));  // canonical integer 1 / Dtot
+        hipLaunchKernelGGL(grand_product_finish_kernel<P>, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, n + 1, pn, sd, dinv, (uint32_t*)out);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = fail(ZK_ERR_HIP, "grand product: finish failed");
+    } while (0);
+    (void)hipFree(work);
+    return rc;
+}
+
+// coeffs (n) = q (n - 1) * (X - root) + rem:  b_k = c_k root^k, SS_j = sum_{k >= j} b_k, q_j = SS_{j+1} root^-(j+1), rem = SS_0
+template <class P>
+static int div_linear_dev_impl(uint64_t n, const void* coeffs, const uint64_t* root_c, void* q, uint64_t* rem, hipStream_t st) {
+    const size_t eb = P::W * 4;
+    uint32_t* r = reinterpret_cast<uint32_t*>(rem);
+    for (int k = 0; k < P::W; ++k) r[k] = 0;
+    if (n == 0) return ZK_OK;
+    Fp<P> root_m = fp_from_canonical<P>(reinterpret_cast<const uint32_t*>(root_c));
+    if (fp_is_zero<P>(root_m)) {  // division by X: a shift
+        ZK_HIP(hipMemcpyAsync(r, coeffs, eb, hipMemcpyDeviceToHost, st));
+        if (n > 1) ZK_HIP(hipMemcpyAsync(q, (const uint32_t*)coeffs + P::W, (n - 1) * eb, hipMemcpyDeviceToDevice, st));
+        ZK_HIP(hipStreamSynchronize(st));
+        return ZK_OK;
+    }
+    uint32_t* work = nullptr;  // b / SS (n) | partials
+    ZK_HIP(hipMalloc(&work, (n + SCAN_MAX_PARTIALS) * eb));
+    uint32_t* partial = work + n * P::W;
+    int rc = ZK_OK;
+    do {
+        const uint32_t chunk = 16;
+        const unsigned blocks = (unsigned)(((n + chunk - 1) / chunk + 255) / 256);
+        hipLaunchKernelGGL(geom_scale_kernel<P>, dim3(blocks), dim3(256), 0, st, n, chunk, (const uint32_t*)coeffs, fp_one<P>(), root_m, work);
+        if ((rc = inclusive_scan<P, ScanAdd>(n, 1, work, work, partial, st))) break;
+        if (hipMemcpyAsync(r, work, eb, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = fail(ZK_ERR_HIP, "div_linear: copy back failed"); break; }
+        if (n > 1) {
+            Fp<P> rinv_m = fp_inv<P>(root_m);
+            const unsigned qb = (unsigned)(((n - 1 + chunk - 1) / chunk + 255) / 256);
+            hipLaunchKernelGGL(geom_scale_kernel<P>, dim3(qb), dim3(256), 0, st, n - 1, chunk, work + P::W, rinv_m, rinv_m, (uint32_t*)q);
+        }
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = fail(ZK_ERR_HIP, "div_linear: kernel failed");
+    } while (0);
+    (void)hipFree(work);
+    return rc;
+}
+
 // ---- host wrappers ------------------------------------------------------------------------------------
 
 template <class P>
@@ -264,6 +458,18 @@ int zk_vec_is_zero_dev(int curve, uint64_t n, const void* d_x, int* is_zero, voi
 
 int zk_poly_eval_dev(int curve, uint64_t n, const void* d_coeffs, const uint64_t* x, uint64_t* out, void* stream) {
 #define CALL(P) return poly_eval_impl_dev<P>(n, d_coeffs, x, out, (hipStream_t)stream)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_plonk_grand_product_dev(int curve, uint64_t n, const void* d_num, const void* d_den, void* d_out, void* stream) {
+#define CALL(P) return grand_product_dev_impl<P>(n, d_num, d_den, d_out, (hipStream_t)stream)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_poly_div_linear_dev(int curve, uint64_t n, const void* d_coeffs, const uint64_t* root, void* d_q, uint64_t* rem, void* stream) {
+#define CALL(P) return div_linear_dev_impl<P>(n, d_coeffs, root, d_q, rem, (hipStream_t)stream)
     ZK_DISPATCH_FR(curve, CALL);
 #undef CALL
 }

@@ -187,6 +187,19 @@ class FrOps:
         self.add_at(cur, 0, value)
         vec.upload(cur, i)
 
+    def d_copy(self, n, src_ptr, dst_ptr):
+        N.check(N.load().zk_vec_axpby_dev(self.cid, n, N.u64p(self.one(1)), src_ptr, None, None, None, dst_ptr, None))
+
+    def d_grand_product(self, n, num_ptr, den_ptr, out_ptr):
+        """out (n + 1): out[0] = 1, out[i+1] = out[i] * num[i] / den[i]"""
+        N.check(N.load().zk_plonk_grand_product_dev(self.cid, n, num_ptr, den_ptr, out_ptr, None))
+
+    def d_div_linear(self, n, coeffs_ptr, root, q_ptr):
+        """q (n - 1) = coeffs (n) / (X - root); returns the remainder"""
+        rem = np.zeros(4, dtype=np.uint64)
+        N.check(N.load().zk_poly_div_linear_dev(self.cid, n, coeffs_ptr, N.u64p(self.one(root)), q_ptr, N.u64p(rem), None))
+        return int.from_bytes(rem.tobytes(), "little")
+
     def d_perm_terms(self, n, wires, labels, beta, gamma, out_ptr):
         arr = ctypes.c_void_p * 3
         N.check(N.load().zk_plonk_perm_terms_dev(self.cid, n, arr(*wires), arr(*labels), N.u64p(self.one(beta)), N.u64p(self.one(gamma)),

@@ -16,10 +16,10 @@ How the prover is organised here (the reference multiplies coefficient-form poly
     (the reference's own `coset_fft` offsets by the domain generator, which maps H_4n onto itself, so the coset here is
     formed explicitly: coefficients are scaled by g^i, g the field's multiplicative generator, before a plain NTT);
   * z(omega X) on the coset is z's evaluation vector rotated by 4n / n = four places; no second transform;
-  * vectors stay in HBM for the whole proof (the witness goes up once; a few blinded coefficients, the grand-product
-    terms and the two opening numerators come down); evaluations at zeta are a device reduction, the linearisation is
-    a chain of device multiply-adds, the commitments read their scalars in place;
-  * what is still sequential on the host (C++, zk_fr_*): the grand product and the two divisions by X - zeta.
+  * vectors stay in HBM for the whole proof (the witness goes up once; only single coefficients and field elements
+    come down): the grand product is two product scans + one inversion, evaluations at zeta are a device reduction,
+    the linearisation a chain of device multiply-adds, division by X - zeta a rescale + suffix-sum scan + rescale,
+    and the commitments read their scalars in place.
 """
 
 import numpy as np
@@ -232,9 +232,11 @@ class Plonk:
         wire_ptrs = [c.ptr() for c in col_d]
         V.d_perm_terms(n, wire_ptrs, [v.ptr() for v in dev["id_labels"]], beta, gamma, g1.ptr())
         V.d_perm_terms(n, wire_ptrs, [v.ptr() for v in dev["sigma_labels"]], beta, gamma, g2.ptr())
-        acc = V.grand_product(g1.download(), g2.download())
-        assert V.int_at(acc, n) == 1, "Copy constraints are not satisfied"
-        z = V.d_from(acc[:n], m)
+        acc = DevVec(n + 1, zero=False)
+        V.d_grand_product(n, g1.ptr(), g2.ptr(), acc.ptr())
+        assert V.int_at(acc.download(1, n), 0) == 1, "Copy constraints are not satisfied"
+        z = DevVec(m)
+        V.d_copy(n, acc.ptr(), z.ptr())
         V.d_ntt(z, n, inverse=True)
         self._blind(z, n, blind[6:9])
         tau_z = self._commit_dev(z, n + 3)
@@ -299,13 +301,12 @@ class Plonk:
         # constant and X^n corrections: PI(zeta), the sigma_3 / L1 constants, the quotient blinding, the opening values
         V.d_add_at(lin, 0, pi_zeta - alpha * f2 * (zc + gamma) - a2l1 + w_mid * blind[9] + w_hi * blind[10] - shift)
         V.d_add_at(lin, n, -zh_zeta * blind[9] - w_mid * blind[10])
-        w_zeta, rem = V.div_linear(lin.download(), zeta)
-        assert rem == 0
-        z_host = z.download(n + 3)
-        V.add_at(z_host, 0, -zzw)
-        w_zeta_omega, rem = V.div_linear(z_host, zeta * omega % r)
-        assert rem == 0
-        tau_w_zeta, tau_w_zeta_omega = self._commit(w_zeta), self._commit(w_zeta_omega)
+        quot = DevVec(n + 5, zero=False)
+        assert V.d_div_linear(n + 6, lin.ptr(), zeta, quot.ptr()) == 0
+        tau_w_zeta = self._commit_dev(quot, n + 5)
+        V.d_add_at(z, 0, -zzw)
+        assert V.d_div_linear(n + 3, z.ptr(), zeta * omega % r, quot.ptr()) == 0
+        tau_w_zeta_omega = self._commit_dev(quot, n + 2)
 
         return Proof(tau_w[0], tau_w[1], tau_w[2], tau_z, tau_t[0], tau_t[1], tau_t[2], tau_w_zeta, tau_w_zeta_omega,
                      za, zb, zc, zs1, zs2, zzw)
