@@ -47,6 +47,7 @@ def main():
                     "fixed-base MSM, NTT 2^22, Groth16 prove 2^20")
     ap.add_argument("--prove-log-n", type=int, default=20)
     ap.add_argument("--precompute", action="store_true", help="plan flag ZK_MSM_PRECOMPUTE (fixed-base table 2^(cw) P_i, shared buckets)")
+    ap.add_argument("--plonk-log-n", type=int, default=18, help="gates (log2) of the PlonK prove in `extra`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -311,6 +312,29 @@ def extra_metrics(lib, torch, dev, args, bases, d_scalars, expected):
 
     # (3) Groth16 prove on the benchmark chain circuit (BASELINE config 4), witness as host limb arrays
     out.update(prove_metric(torch, args, None, 1))
+
+    # (4) PlonK prove on the same chain as gates, witness as a host limb array
+    from zksnake_amd.arithmetization import Plonkish
+    from zksnake_amd.plonk import Plonk
+    gn = 1 << args.plonk_log_n
+    r = constant.BN254_SCALAR_FIELD
+    gates, perm, pub, priv = W.plonk_chain_gates(gn, r)
+    plonk = Plonk(Plonkish.from_gates(gates["L"], gates["R"], gates["O"], gates["M"], gates["C"], perm, "BN254"), "BN254")
+    plonk._tau = W.field_stream(W.SEED_PROVE, 1, r)[1][0]
+    plonk._blinding = W.field_stream(W.SEED_PROVE, 11, r, offset=1)[1]
+    plonk.setup()
+    witness = N.ints_to_limbs(priv)
+    times = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pproof = plonk.prove(pub, witness)
+        times.append((time.perf_counter() - t0) * 1e3)
+    ok = plonk.verify(pproof, pub)
+    out[f"plonk_prove_bn254_2^{args.plonk_log_n}"] = {"ms": round(min(times[1:]), 3), "first_ms_incl_key_columns": round(times[0], 1), "verifies": bool(ok),
+                                                     "proof_sha256": __import__("hashlib").sha256(pproof.to_bytes()).hexdigest()}
+    if not ok:
+        raise SystemExit("PlonK proof does not verify")
     return out
 
 
