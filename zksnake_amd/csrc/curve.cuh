@@ -66,7 +66,7 @@ ZK_HD XYZZ<F> xyzz_dbl_affine(const Affine<F>& p) {
     T xx = F::sqr(p.x);
     T M = F::add(F::dbl(xx), xx);
     T X3 = F::sub(F::sqr(M), F::dbl(S));
-    T Y3 = F::sub(F::mul(M, F::sub_for_mul(S, X3)), F::mul(W, p.y));
+    T Y3 = F::mul_diff(M, S, X3, W, p.y);
     return {X3, Y3, V, W};
 }
 
@@ -82,7 +82,7 @@ ZK_HD XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
     T xx = F::sqr(p.X);
     T M = F::add(F::dbl(xx), xx);
     T X3 = F::sub(F::sqr(M), F::dbl(S));
-    T Y3 = F::sub(F::mul(M, F::sub_for_mul(S, X3)), F::mul(W, p.Y));
+    T Y3 = F::mul_diff(M, S, X3, W, p.Y);
     T ZZ3 = F::mul(V, p.ZZ);
     T ZZZ3 = F::mul(W, p.ZZZ);
     return {X3, Y3, ZZ3, ZZZ3};
@@ -110,7 +110,7 @@ ZK_HD void xyzz_add_affine(XYZZ<F>& acc, const Affine<F>& q) {
     T PPP = F::mul(Pd, PP);
     T Q = F::mul(acc.X, PP);
     T X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-    T Y3 = F::sub(F::mul(R, F::sub_for_mul(Q, X3)), F::mul(acc.Y, PPP));
+    T Y3 = F::mul_diff(R, Q, X3, acc.Y, PPP);
     acc.X = X3;
     acc.Y = Y3;
     acc.ZZ = F::mul(acc.ZZ, PP);
@@ -164,7 +164,7 @@ __device__ __forceinline__ void xyzz_add_affine_mem(XYZZ<F>& acc, const uint32_t
     T PPP = F::mul(Pd, PP);
     T Q = F::mul(acc.X, PP);
     T X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-    acc.Y = F::sub(F::mul(R, F::sub_for_mul(Q, X3)), F::mul(acc.Y, PPP));
+    acc.Y = F::mul_diff(R, Q, X3, acc.Y, PPP);
     acc.X = X3;
     acc.ZZ = F::mul(acc.ZZ, PP);
     acc.ZZZ = F::mul(acc.ZZZ, PPP);
@@ -191,7 +191,7 @@ ZK_HD XYZZ<F> xyzz_add(const XYZZ<F>& p, const XYZZ<F>& q) {
     T PPP = F::mul(Pd, PP);
     T Q = F::mul(U1, PP);
     T X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-    T Y3 = F::sub(F::mul(R, F::sub_for_mul(Q, X3)), F::mul(S1, PPP));
+    T Y3 = F::mul_diff(R, Q, X3, S1, PPP);
     T ZZ3 = F::mul(F::mul(p.ZZ, q.ZZ), PP);
     T ZZZ3 = F::mul(F::mul(p.ZZZ, q.ZZZ), PPP);
     return {X3, Y3, ZZ3, ZZZ3};

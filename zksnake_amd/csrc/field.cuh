@@ -155,6 +155,18 @@ ZK_HD Fp<P> fp_sub_lazy(const Fp<P>& a, const Fp<P>& b) {
     return r;
 }
 
+// 4p - b with the same borrow-proof limbs: a carry-free negation, valid as one operand of a product
+template <class P>
+ZK_HD Fp<P> fp_neg_lazy(const Fp<P>& b) {
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        uint32_t c = P::P4[i] + (i < P::N - 1 ? (1u << LIMB_BITS) : 0u) - (i > 0 ? 1u : 0u);
+        r.v[i] = c - b.v[i];
+    }
+    return r;
+}
+
 template <class P>
 ZK_HD Fp<P> fp_neg(const Fp<P>& a) {
     return fp_sub<P>(fp_zero<P>(), a);
@@ -460,6 +472,14 @@ struct FpOps {
         if constexpr (P::N <= 12) return fp_sub_lazy<P>(a, b);
         else return fp_sub<P>(a, b);
     }
+    // m * (s - x) - w * y with ONE Montgomery reduction (the Y3 of every addition / doubling formula).  With limbs
+    // < 3*2^29 for the lazy difference and < 2*2^29 for the lazy negation a column holds N*(3+2+1)*2^58 < 2^64 for
+    // N <= 10, so both stay carry-free; wider fields use ordinary operands (3N products fit up to N = 14).
+    // Value: (2p*6p + 4p*2p)/R + p < 2p since R/p >= 70.
+    static ZK_HD T mul_diff(const T& m, const T& s, const T& x, const T& w, const T& y) {
+        if constexpr (P::N <= 10) return fp_mul2<P>(m, fp_sub_lazy<P>(s, x), fp_neg_lazy<P>(w), y);
+        else return fp_mul2<P>(m, fp_sub<P>(s, x), fp_neg<P>(w), y);
+    }
     static ZK_HD T mul(const T& a, const T& b) { return fp_mul<P>(a, b); }
     static ZK_HD T sqr(const T& a) { return fp_sqr<P>(a); }
     static ZK_HD T neg(const T& a) { return fp_neg<P>(a); }
@@ -484,6 +504,9 @@ struct Fp2Ops {
     static ZK_HD T add(const T& a, const T& b) { return fp2_add<P>(a, b); }
     static ZK_HD T sub(const T& a, const T& b) { return fp2_sub<P>(a, b); }
     static ZK_HD T sub_for_mul(const T& a, const T& b) { return fp2_sub<P>(a, b); }  // fp_mul2 has no spare room
+    static ZK_HD T mul_diff(const T& m, const T& s, const T& x, const T& w, const T& y) {
+        return fp2_sub<P>(fp2_mul<P>(m, fp2_sub<P>(s, x)), fp2_mul<P>(w, y));
+    }
     static ZK_HD T mul(const T& a, const T& b) { return fp2_mul<P>(a, b); }
     static ZK_HD T sqr(const T& a) { return fp2_sqr<P>(a); }
     static ZK_HD T neg(const T& a) { return fp2_neg<P>(a); }
