@@ -171,7 +171,7 @@ struct ScanMul {
 };
 
 template <class P, class Op>
-__global__ __launch_bounds__(256) void scan_reduce_kernel(uint64_t n, uint32_t chunk, int reverse, const uint32_t* __restrict__ in,
+__global__ __launch_bounds__(256) void fr_scan_reduce_kernel(uint64_t n, uint32_t chunk, int reverse, const uint32_t* __restrict__ in,
                                                           uint32_t* __restrict__ partial) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t lo = t * chunk;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(uint64_t n, uint32_t c
 
 // in place: partial[t] <- partial[0] o .. o partial[t-1]   (exclusive), count <= SCAN_MAX_PARTIALS, one workgroup
 template <class P, class Op>
-__global__ __launch_bounds__(256) void scan_block_kernel(uint32_t count, uint32_t* __restrict__ partial) {
+__global__ __launch_bounds__(256) void fr_scan_block_kernel(uint32_t count, uint32_t* __restrict__ partial) {
     __shared__ uint32_t lds[P::N][256];
     const uint32_t per = (count + 255) / 256;
     const uint32_t lo = threadIdx.x * per;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void scan_block_kernel(uint32_t count, uint32_
 
 // inclusive scan: out[idx(k)] = e_0 o .. o e_k over the (possibly mirrored) order
 template <class P, class Op>
-__global__ __launch_bounds__(256) void scan_apply_kernel(uint64_t n, uint32_t chunk, int reverse, const uint32_t* __restrict__ in,
+__global__ __launch_bounds__(256) void fr_scan_apply_kernel(uint64_t n, uint32_t chunk, int reverse, const uint32_t* __restrict__ in,
                                                          const uint32_t* __restrict__ partial, uint32_t* __restrict__ out) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t lo = t * chunk;
@@ -273,9 +273,9 @@ static int inclusive_scan(uint64_t n, int reverse, const uint32_t* in, uint32_t*
     if (chunk < 16) chunk = 16;
     const uint64_t threads = (n + chunk - 1) / chunk;
     const unsigned blocks = (unsigned)((threads + 255) / 256);
-    hipLaunchKernelGGL((scan_reduce_kernel<P, Op>), dim3(blocks), dim3(256), 0, st, n, (uint32_t)chunk, reverse, in, partial);
-    hipLaunchKernelGGL((scan_block_kernel<P, Op>), dim3(1), dim3(256), 0, st, (uint32_t)threads, partial);
-    hipLaunchKernelGGL((scan_apply_kernel<P, Op>), dim3(blocks), dim3(256), 0, st, n, (uint32_t)chunk, reverse, in, partial, out);
+    hipLaunchKernelGGL((fr_scan_reduce_kernel<P, Op>), dim3(blocks), dim3(256), 0, st, n, (uint32_t)chunk, reverse, in, partial);
+    hipLaunchKernelGGL((fr_scan_block_kernel<P, Op>), dim3(1), dim3(256), 0, st, (uint32_t)threads, partial);
+    hipLaunchKernelGGL((fr_scan_apply_kernel<P, Op>), dim3(blocks), dim3(256), 0, st, n, (uint32_t)chunk, reverse, in, partial, out);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
