@@ -436,7 +436,9 @@ template <class P> ZK_HD Fp2<P> fp2_dbl(const Fp2<P>& a) { return {fp_dbl<P>(a.c
 // additions, because an addition costs ~1/4 of a product on this machine.
 template <class P>
 ZK_HD Fp2<P> fp2_mul(const Fp2<P>& a, const Fp2<P>& b) {
-    Fp<P> na1 = fp_neg<P>(a.c1);
+    // -a1 as the carry-free 4p - a1 (limbs < 2*2^29): the columns of fp_mul2 then hold N*(1 + 2 + 1)*2^58 < 2^64
+    // for N <= 14, and (2p*2p + 4p*2p)/R + p < 2p
+    Fp<P> na1 = fp_neg_lazy<P>(a.c1);
     return {fp_mul2<P>(a.c0, b.c0, na1, b.c1), fp_mul2<P>(a.c0, b.c1, a.c1, b.c0)};
 }
 
