@@ -136,38 +136,81 @@ __device__ __forceinline__ Affine<F> load_affine_row(const uint32_t* p) {
 template <class F>
 __device__ __forceinline__ void xyzz_add_affine_mem(XYZZ<F>& acc, const uint32_t* src, bool negate) {
     typedef typename F::T T;
-    T U2, S2;
-    {
-        Affine<F> q = load_affine_row<F>(src);
-        if (aff_is_inf<F>(q)) return;
-        if (negate) q.y = F::neg(q.y);
-        if (xyzz_is_inf<F>(acc)) {
-            acc = {q.x, q.y, F::one(), F::one()};
+    if constexpr (F::RELAXED) {
+        // Base-field groups: the accumulator's X lives in [0, 4p) (Y, ZZ, ZZZ in [0, 2p)) and the differences feed
+        // products without the range selection of F::sub -- every consumer of an accumulator coordinate is a product,
+        // which tolerates operands up to (a/p)(b/p) <= R/p (>= 168 for the two base fields):
+        //   P = U2 - X + 4p < 6p,  R = S2 - Y + 2p < 4p,  PP = P^2 (36),  PPP = P PP (12),  Q = X PP (8),  R^2 (16),
+        //   X3 = R^2 - PPP + 2p - 2Q brought into [0, 4p),  Y3 = R (Q - X3) - Y PPP as one double product.
+        T U2, S2;
+        {
+            Affine<F> q = load_affine_row<F>(src);
+            if (aff_is_inf<F>(q)) return;
+            if (xyzz_is_inf<F>(acc)) {
+                acc = {q.x, negate ? F::neg(q.y) : q.y, F::one(), F::one()};
+                return;
+            }
+            U2 = F::mul(q.x, acc.ZZ);
+            T ny = F::neg_for_mul(q.y);  // 4p - y, limbs < 2*2^29: one operand of the next product only
+#pragma unroll
+            for (int i = 0; i < F::REGS; ++i) ny.v[i] = negate ? ny.v[i] : q.y.v[i];
+            S2 = F::mul(ny, acc.ZZZ);
+        }
+        T Pd = F::template sub_k<4>(U2, acc.X);
+        T R = F::template sub_k<2>(S2, acc.Y);
+        T PP = F::sqr(Pd);
+        T RR = F::sqr(R);
+        if (F::is_zero(PP)) {  // P = 0 mod p (p is prime): same x
+            if (F::is_zero(RR)) {
+                Affine<F> q = load_affine_row<F>(src);
+                if (negate) q.y = F::neg(q.y);
+                acc = xyzz_dbl_affine<F>(q);
+            } else {
+                acc = xyzz_inf<F>();
+            }
             return;
         }
-        U2 = F::mul(q.x, acc.ZZ);
-        S2 = F::mul(q.y, acc.ZZZ);
-    }
-    T Pd = F::sub(U2, acc.X);
-    T R = F::sub(S2, acc.Y);
-    if (F::is_zero(Pd)) {
-        if (F::is_zero(R)) {
+        T PPP = F::mul(Pd, PP);
+        T Q = F::mul(acc.X, PP);
+        T X3 = F::x3_sel4(F::template sub_k<2>(RR, PPP), Q);
+        acc.Y = F::y3_relaxed(R, Q, X3, acc.Y, PPP);
+        acc.X = X3;
+        acc.ZZ = F::mul(acc.ZZ, PP);
+        acc.ZZZ = F::mul(acc.ZZZ, PPP);
+    } else {
+        T U2, S2;
+        {
             Affine<F> q = load_affine_row<F>(src);
+            if (aff_is_inf<F>(q)) return;
             if (negate) q.y = F::neg(q.y);
-            acc = xyzz_dbl_affine<F>(q);
-        } else {
-            acc = xyzz_inf<F>();
+            if (xyzz_is_inf<F>(acc)) {
+                acc = {q.x, q.y, F::one(), F::one()};
+                return;
+            }
+            U2 = F::mul(q.x, acc.ZZ);
+            S2 = F::mul(q.y, acc.ZZZ);
         }
-        return;
+        T Pd = F::sub(U2, acc.X);
+        T R = F::sub(S2, acc.Y);
+        if (F::is_zero(Pd)) {
+            if (F::is_zero(R)) {
+                Affine<F> q = load_affine_row<F>(src);
+                if (negate) q.y = F::neg(q.y);
+                acc = xyzz_dbl_affine<F>(q);
+            } else {
+                acc = xyzz_inf<F>();
+            }
+            return;
+        }
+        T PP = F::sqr(Pd);
+        T PPP = F::mul(Pd, PP);
+        T Q = F::mul(acc.X, PP);
+        T X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+        acc.Y = F::mul_diff(R, Q, X3, acc.Y, PPP);
+        acc.X = X3;
+        acc.ZZ = F::mul(acc.ZZ, PP);
+        acc.ZZZ = F::mul(acc.ZZZ, PPP);
     }
-    T PP = F::sqr(Pd);
-    T PPP = F::mul(Pd, PP);
-    T Q = F::mul(acc.X, PP);
-    T X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-    acc.Y = F::mul_diff(R, Q, X3, acc.Y, PPP);
-    acc.X = X3;
-    acc.ZZ = F::mul(acc.ZZ, PP);
-    acc.ZZZ = F::mul(acc.ZZZ, PPP);
 }
 #endif
 

@@ -155,6 +155,68 @@ ZK_HD Fp<P> fp_sub_lazy(const Fp<P>& a, const Fp<P>& b) {
     return r;
 }
 
+// ---- "relaxed" forms for the MSM inner loop: no range selection, so half the instructions of fp_add / fp_sub.
+// Products tolerate operands well above 2p ((a/p)(b/p) <= R/p), so a difference may stay in (0, (K+2)p). ------
+
+// a - b + K p (K = 2 or 4) with the carries propagated (normalized limbs), for a < 2p and 0 <= b < K p: value in (0, (K+2)p)
+template <class P, int K>
+ZK_HD Fp<P> fp_sub_k(const Fp<P>& a, const Fp<P>& b) {
+    static_assert(K == 2 || K == 4, "K p constants exist for K = 2, 4");
+    constexpr int N = P::N;
+    Fp<P> r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        int32_t x = (int32_t)a.v[i] - (int32_t)b.v[i] + (int32_t)(K == 2 ? P::P2[i] : P::P4[i]) + c;
+        if (i < N - 1) {
+            r.v[i] = (uint32_t)x & LIMB_MASK;
+            c = x >> LIMB_BITS;
+        } else {
+            r.v[i] = (uint32_t)x;
+        }
+    }
+    return r;
+}
+
+// t - 2q brought into [0, 4p) for t in [0, 4p), q in [0, 2p): both candidates (x, x + 4p) in one pass, like fp_sub
+template <class P>
+ZK_HD Fp<P> fp_sub_twice_sel4(const Fp<P>& t, const Fp<P>& q) {
+    constexpr int N = P::N;
+    Fp<P> s, u;
+    int32_t cs = 0, cu = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        int32_t x = (int32_t)t.v[i] - 2 * (int32_t)q.v[i];
+        int32_t a = x + cs;
+        int32_t b = x + (int32_t)P::P4[i] + cu;
+        if (i < N - 1) {
+            s.v[i] = (uint32_t)a & LIMB_MASK;
+            cs = a >> LIMB_BITS;
+            u.v[i] = (uint32_t)b & LIMB_MASK;
+            cu = b >> LIMB_BITS;
+        } else {
+            s.v[i] = (uint32_t)a;
+            u.v[i] = (uint32_t)b;
+        }
+    }
+    const bool neg = (int32_t)s.v[N - 1] < 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) s.v[i] = neg ? u.v[i] : s.v[i];
+    return s;
+}
+
+// a - b + 8p, carry-free with borrow-proof limbs (< 3*2^29), for b < 4p... any normalized b below 8p; one product operand only
+template <class P>
+ZK_HD Fp<P> fp_sub_lazy8(const Fp<P>& a, const Fp<P>& b) {
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        uint32_t c = P::P8[i] + (i < P::N - 1 ? (1u << LIMB_BITS) : 0u) - (i > 0 ? 1u : 0u);
+        r.v[i] = a.v[i] + c - b.v[i];
+    }
+    return r;
+}
+
 // 4p - b with the same borrow-proof limbs: a carry-free negation, valid as one operand of a product
 template <class P>
 ZK_HD Fp<P> fp_neg_lazy(const Fp<P>& b) {
@@ -493,6 +555,19 @@ struct FpOps {
     static ZK_HD void to_canonical(uint32_t* w, const T& a) { fp_to_canonical<P>(w, a); }
     static ZK_HD T load(const uint32_t* w) { return fp_load<P>(w); }
     static ZK_HD void store(uint32_t* w, const T& a) { fp_store<P>(w, a); }
+
+    // ---- relaxed-range pieces of the bucket-accumulation step (curve.cuh, xyzz_add_affine_mem) ----
+    static constexpr bool RELAXED = true;
+    static ZK_HD T neg_for_mul(const T& a) { return fp_neg_lazy<P>(a); }                 // 4p - a, carry-free
+    template <int K> static ZK_HD T sub_k(const T& a, const T& b) { return fp_sub_k<P, K>(a, b); }
+    static ZK_HD T x3_sel4(const T& t, const T& q) { return fp_sub_twice_sel4<P>(t, q); }
+    // r * (q - x3) - y * ppp with r < 4p, x3 < 4p, the rest < 2p; one reduction.
+    // N <= 10: q - x3 + 8p and 4p - y carry-free: columns N (3 + 2 + 1) 2^58 < 2^64, value (4p 10p + 4p 2p)/R + p < 2p.
+    // wider: q - x3 + 4p normalized, 4p - y carry-free: columns N (1 + 2 + 1) 2^58 < 2^64 for N <= 14.
+    static ZK_HD T y3_relaxed(const T& r, const T& q, const T& x3, const T& y, const T& ppp) {
+        if constexpr (P::N <= 10) return fp_mul2<P>(r, fp_sub_lazy8<P>(q, x3), fp_neg_lazy<P>(y), ppp);
+        else return fp_mul2<P>(r, fp_sub_k<P, 4>(q, x3), fp_neg_lazy<P>(y), ppp);
+    }
 };
 
 template <class P>
@@ -505,6 +580,7 @@ struct Fp2Ops {
     static ZK_HD T one() { return fp2_one<P>(); }
     static ZK_HD T add(const T& a, const T& b) { return fp2_add<P>(a, b); }
     static ZK_HD T sub(const T& a, const T& b) { return fp2_sub<P>(a, b); }
+    static constexpr bool RELAXED = false;
     static ZK_HD T sub_for_mul(const T& a, const T& b) { return fp2_sub<P>(a, b); }  // fp_mul2 has no spare room
     static ZK_HD T mul_diff(const T& m, const T& s, const T& x, const T& w, const T& y) {
         return fp2_sub<P>(fp2_mul<P>(m, fp2_sub<P>(s, x)), fp2_mul<P>(w, y));
