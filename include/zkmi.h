@@ -165,6 +165,8 @@ int zk_point_bytes(int curve, int group);
 /* out = a*x + b*y + c (element-wise; b and d_y may both be NULL, c may be NULL); out may alias x or y */
 int zk_vec_axpby_dev(int curve, uint64_t n, const uint64_t* a, const void* d_x, const uint64_t* b, const void* d_y, const uint64_t* c,
                      void* d_out, void* stream);
+/* dst[i] = src[offset + i*stride], i < n: one column of the flat witness [a0, b0, c0, a1, ...] (protocol.py:167-169) */
+int zk_vec_gather_dev(int curve, uint64_t n, const void* d_src, uint64_t stride, uint64_t offset, void* d_dst, void* stream);
 /* *is_zero = 1 when all n elements are zero (synchronises the stream) */
 int zk_vec_is_zero_dev(int curve, uint64_t n, const void* d_x, int* is_zero, void* stream);
 /* out = sum_i coeffs[i] x^i (Polynomial.__call__, src/bn254/polynomial.rs:491-516); synchronises the stream */

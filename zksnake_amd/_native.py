@@ -78,6 +78,7 @@ SIGNATURES = {
     "zk_point_decompress": (_i, [_i, _i, _u8p, _u64p]),
     "zk_point_bytes": (_i, [_i, _i]),
     "zk_vec_axpby_dev": (_i, [_i, _u64, _u64p, _vp, _u64p, _vp, _u64p, _vp, _vp]),
+    "zk_vec_gather_dev": (_i, [_i, _u64, _vp, _u64, _u64, _vp, _vp]),
     "zk_vec_is_zero_dev": (_i, [_i, _u64, _vp, ctypes.POINTER(_i), _vp]),
     "zk_poly_eval_dev": (_i, [_i, _u64, _vp, _u64p, _u64p, _vp]),
     "zk_plonk_grand_product_dev": (_i, [_i, _u64, _vp, _vp, _vp, _vp]),

@@ -42,6 +42,16 @@ __global__ __launch_bounds__(256) void axpby_kernel(uint64_t n, Fp<P> a_m, const
     store_fr<P>(out + i * P::W, fp_reduce_full<P>(v));
 }
 
+// out[i] = in[offset + i * stride]: de-interleaves the flat PlonK witness [a0, b0, c0, a1, ..] into its three columns
+template <class P>
+__global__ __launch_bounds__(256) void gather_kernel(uint64_t n, const uint4* __restrict__ in, uint64_t stride, uint64_t offset, uint4* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int V = P::W / 4;  // 16-byte vectors per element
+    if (i >= n * V) return;
+    const uint64_t e = i / V, part = i % V;
+    out[i] = in[(offset + e * stride) * V + part];
+}
+
 template <class P>
 __global__ __launch_bounds__(256) void is_zero_kernel(uint64_t n_vec4, const uint4* __restrict__ x, int* flag) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -446,6 +456,20 @@ extern "C" {
 int zk_vec_axpby_dev(int curve, uint64_t n, const uint64_t* a, const void* d_x, const uint64_t* b, const void* d_y, const uint64_t* c,
                      void* d_out, void* stream) {
 #define CALL(P) return axpby_impl<P>(n, a, d_x, b, d_y, c, d_out, (hipStream_t)stream)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_vec_gather_dev(int curve, uint64_t n, const void* d_src, uint64_t stride, uint64_t offset, void* d_dst, void* stream) {
+#define CALL(P)                                                                                                            \
+    {                                                                                                                      \
+        if (n == 0) return ZK_OK;                                                                                          \
+        const uint64_t nv = n * (P::W / 4);                                                                                \
+        hipLaunchKernelGGL(gather_kernel<P>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n,     \
+                           (const uint4*)d_src, stride, offset, (uint4*)d_dst);                                            \
+        ZK_HIP(hipGetLastError());                                                                                         \
+        return ZK_OK;                                                                                                      \
+    }
     ZK_DISPATCH_FR(curve, CALL);
 #undef CALL
 }

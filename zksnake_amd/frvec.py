@@ -16,14 +16,50 @@ from .device import DeviceBuffer
 _CID = {BN254_SCALAR_FIELD: N.CURVE_BN254, BLS12_381_SCALAR_FIELD: N.CURVE_BLS12_381}
 
 
+# Released vectors go back to a size-keyed pool instead of hipFree (which synchronises the device, ~0.2 ms each, and a
+# proof allocates a few dozen vectors of the same handful of sizes).  All vector kernels are issued on the NULL stream,
+# so reuse is stream-ordered and safe.
+_POOL = {}
+_POOL_BYTES = [0]
+_POOL_LIMIT = 32 << 30
+
+
+def release_pool():
+    """free every pooled device buffer"""
+    for bufs in _POOL.values():
+        for buf in bufs:
+            buf.free()
+    _POOL.clear()
+    _POOL_BYTES[0] = 0
+
+
 class DevVec:
     """n canonical Fr elements in HBM"""
 
     def __init__(self, n, zero=True):
         self.n = n
-        self.buf = DeviceBuffer(32 * max(n, 1))
+        nbytes = 32 * max(n, 1)
+        bufs = _POOL.get(nbytes)
+        if bufs:
+            self.buf = bufs.pop()
+            _POOL_BYTES[0] -= nbytes
+        else:
+            self.buf = DeviceBuffer(nbytes)
         if zero:
             self.buf.zero()
+
+    def __del__(self):
+        try:
+            buf, self.buf = self.buf, None
+            if buf is None or buf.ptr is None:
+                return
+            if _POOL_BYTES[0] + buf.nbytes <= _POOL_LIMIT:
+                _POOL.setdefault(buf.nbytes, []).append(buf)
+                _POOL_BYTES[0] += buf.nbytes
+            else:
+                buf.free()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
     def ptr(self, offset=0):
         assert 0 <= offset <= self.n
@@ -186,6 +222,10 @@ class FrOps:
         cur = vec.download(1, i)
         self.add_at(cur, 0, value)
         vec.upload(cur, i)
+
+    def d_gather(self, n, src_ptr, stride, offset, dst_ptr):
+        """dst[i] = src[offset + i * stride]"""
+        N.check(N.load().zk_vec_gather_dev(self.cid, n, src_ptr, stride, offset, dst_ptr, None))
 
     def d_copy(self, n, src_ptr, dst_ptr):
         N.check(N.load().zk_vec_axpby_dev(self.cid, n, N.u64p(self.one(1)), src_ptr, None, None, None, dst_ptr, None))

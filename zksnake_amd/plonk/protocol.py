@@ -176,15 +176,8 @@ class Plonk:
         blind = list(self._blinding) if self._blinding is not None else [get_random_int(r - 1) for _ in range(11)]
 
         wit = V.limbs(private_witness)
-        cols = []
-        for j in range(3):
-            col = V.zeros(n)
-            part = wit[j::3]
-            col[:part.shape[0]] = part
-            cols.append(col)
-        pi_evals = V.zeros(n)
-        for k, v in public_witness.items():
-            pi_evals[k] = V.one(v)[0]
+        rows = -(-wit.shape[0] // 3)
+        assert rows <= n, "witness is longer than the circuit"
 
         transcript = FiatShamirTranscript(field=r)
         for k in SELECTORS:
@@ -194,10 +187,17 @@ class Plonk:
         for _, v in public_witness.items():
             transcript.append(v)
 
-        # the witness goes up once: as n-domain columns (gate check, grand product) and as the start of the
-        # coefficient vectors (m entries, so the same buffers later feed the coset transforms)
-        col_d = [V.d_from(c) for c in cols]
-        pi_d = V.d_from(pi_evals)
+        # the flat witness goes up once and is de-interleaved on the GPU into the three n-domain columns (gate check, grand
+        # product); the coefficient vectors are m entries long so the same buffers later feed the coset transforms
+        wit_d = V.d_from(wit, 3 * rows)
+        col_d = []
+        for j in range(3):
+            col = DevVec(n, zero=rows < n)
+            V.d_gather((wit.shape[0] - j + 2) // 3, wit_d.ptr(), 3, j, col.ptr())
+            col_d.append(col)
+        pi_d = DevVec(n)
+        for k, v in public_witness.items():
+            pi_d.upload(V.one(v), k)
         qc = dev["q_columns"]
         # the gate identity has to hold on H itself, else the "quotient" is not a polynomial (the reference asserts a
         # zero remainder, protocol.py:347)
@@ -216,11 +216,13 @@ class Plonk:
         # -- round 1: blinded wire polynomials and their commitments ---------------------------------
         wires = []
         for j in range(3):
-            w = V.d_from(cols[j], m)
+            w = DevVec(m)
+            V.d_copy(n, col_d[j].ptr(), w.ptr())
             V.d_ntt(w, n, inverse=True)
             self._blind(w, n, blind[2 * j:2 * j + 2])
             wires.append(w)
-        pi_c = V.d_from(pi_evals, m)
+        pi_c = DevVec(m)
+        V.d_copy(n, pi_d.ptr(), pi_c.ptr())
         V.d_ntt(pi_c, n, inverse=True)
         tau_w = [self._commit_dev(w, n + 2) for w in wires]
         for point in tau_w:
