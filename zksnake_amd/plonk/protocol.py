@@ -52,13 +52,32 @@ class Plonk:
         self.last_timings = {}
 
     # ------------------------------------------------------------------------------------------
-    def _tau_plan(self):
-        """the resident fixed-base MSM plan over the proving key's tau_g1 (all commitments of a proof use it)"""
+    def _tau_plan(self, slot=0):
+        """a resident fixed-base MSM plan over the proving key's tau_g1 (all commitments of a proof use these); slots are
+        independent workspaces, so the commitments of one round can be in flight together"""
         pk, cid = self.proving_key, self.E.curve.curve_id
         if not isinstance(pk.tau_g1, PointArray):
             from .._algebra import _points_to_limbs
             pk.tau_g1 = PointArray(cid, 1, _points_to_limbs(pk.tau_g1, cid, 1))
-        return pk.tau_g1.plan(precompute=True)
+        return pk.tau_g1.plan(slot, precompute=True)
+
+    def _commit_many(self, jobs):
+        """jobs: [(device vector, count, offset)] -> commitments; the MSMs of one round run concurrently on their plans'
+        own streams (the latency-bound reduction of one hides behind the accumulation of the others)"""
+        lib, cid = N.load(), self.E.curve.curve_id
+        from .._algebra import _point_class
+        handles = []
+        for slot, (vec, count, offset) in enumerate(jobs):
+            assert count <= len(self.proving_key.tau_g1), "Constraints are too big for the given g1_tau"
+            h = self._tau_plan(slot)
+            N.check(lib.zk_msm_plan_enqueue(h, count, vec.ptr(offset), 1, 0, 0, N.STREAM_PLAN))
+            handles.append(h)
+        points = []
+        for h in handles:
+            out = np.zeros(N.point_limbs(cid, 1), dtype=np.uint64)
+            N.check(lib.zk_msm_plan_finish(h, N.u64p(out)))
+            points.append(_point_class(cid, 1)._from_limbs(out))
+        return points
 
     def _run_plan(self, count, scalars_ptr, on_device):
         cid = self.E.curve.curve_id
@@ -224,7 +243,7 @@ class Plonk:
         pi_c = DevVec(m)
         V.d_copy(n, pi_d.ptr(), pi_c.ptr())
         V.d_ntt(pi_c, n, inverse=True)
-        tau_w = [self._commit_dev(w, n + 2) for w in wires]
+        tau_w = self._commit_many([(w, n + 2, 0) for w in wires])
         for point in tau_w:
             transcript.append(point)
 
@@ -260,9 +279,8 @@ class Plonk:
         # T = t_lo + X^n t_mid + X^2n t_hi with t_lo += b9 X^n, t_mid += -b9 + b10 X^n, t_hi += -b10: the blinding terms
         # are added on the group side (tau_g1[0] = G, tau_g1[n] = tau^n G)
         G, Gn = pk.tau_g1[0], pk.tau_g1[n]
-        tau_t = [self._commit_dev(t, n) + Gn * blind[9],
-                 self._commit_dev(t, n, n) + G * ((-blind[9]) % r) + Gn * blind[10],
-                 self._commit_dev(t, n + 6, 2 * n) + G * ((-blind[10]) % r)]
+        t_lo, t_mid, t_hi = self._commit_many([(t, n, 0), (t, n, n), (t, n + 6, 2 * n)])
+        tau_t = [t_lo + Gn * blind[9], t_mid + G * ((-blind[9]) % r) + Gn * blind[10], t_hi + G * ((-blind[10]) % r)]
         for point in tau_t:
             transcript.append(point)
 
@@ -303,12 +321,11 @@ class Plonk:
         # constant and X^n corrections: PI(zeta), the sigma_3 / L1 constants, the quotient blinding, the opening values
         V.d_add_at(lin, 0, pi_zeta - alpha * f2 * (zc + gamma) - a2l1 + w_mid * blind[9] + w_hi * blind[10] - shift)
         V.d_add_at(lin, n, -zh_zeta * blind[9] - w_mid * blind[10])
-        quot = DevVec(n + 5, zero=False)
+        quot, quot_w = DevVec(n + 5, zero=False), DevVec(n + 2, zero=False)
         assert V.d_div_linear(n + 6, lin.ptr(), zeta, quot.ptr()) == 0
-        tau_w_zeta = self._commit_dev(quot, n + 5)
         V.d_add_at(z, 0, -zzw)
-        assert V.d_div_linear(n + 3, z.ptr(), zeta * omega % r, quot.ptr()) == 0
-        tau_w_zeta_omega = self._commit_dev(quot, n + 2)
+        assert V.d_div_linear(n + 3, z.ptr(), zeta * omega % r, quot_w.ptr()) == 0
+        tau_w_zeta, tau_w_zeta_omega = self._commit_many([(quot, n + 5, 0), (quot_w, n + 2, 0)])
 
         return Proof(tau_w[0], tau_w[1], tau_w[2], tau_z, tau_t[0], tau_t[1], tau_t[2], tau_w_zeta, tau_w_zeta_omega,
                      za, zb, zc, zs1, zs2, zzw)
