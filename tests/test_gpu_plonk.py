@@ -30,7 +30,7 @@ def _as_oracle_proof(proof, cv):
 
 
 @pytest.mark.parametrize("curve", ["BN254", "BLS12_381"])
-@pytest.mark.parametrize("n", [4, 8, 64])
+@pytest.mark.parametrize("n", [2, 4, 8, 64])
 def test_proof_bytes_equal_oracle(gpu, curve, n):
     cv, gates, perm, pub, priv, pl = _circuit(n, curve)
     assert pl.is_sat(pub, priv)
@@ -80,6 +80,41 @@ def test_random_setup_and_key_round_trips(gpu, curve):
     plonk._blinding = BLIND
     p1, p2 = plonk.prove(pub, priv), other.prove(pub, priv)
     assert p1.to_bytes() == p2.to_bytes() and other.verify(p2, pub)
+
+
+def test_short_witness_and_limb_array_input(gpu):
+    """a witness shorter than the padded circuit (the reference pads a, b, c with zeros, protocol.py:167-169), given as
+    ints or as a limb array: same proof; the device gather against numpy slicing"""
+    import numpy as np
+    from zksnake_amd import _native as N
+    from zksnake_amd.frvec import DevVec, FrOps
+    cv, gates, perm, pub, priv, _ = _circuit(16, "BN254")
+    # drop the last gate row of the witness: its slots are a = out, b = c = 0, so only `a` changes the circuit
+    g = {k: list(v) for k, v in gates.items()}
+    g["L"][15] = 0                                       # row 15 becomes the empty gate ...
+    pub = {}                                             # ... and nothing is public any more
+    perm = list(perm)
+    perm[15], perm[2 * 16 + 14] = 15, 2 * 16 + 14       # a_15 and c_14 are free slots now
+    pl = Plonkish.from_gates(g["L"], g["R"], g["O"], g["M"], g["C"], perm, "BN254")
+    short = priv[:3 * 15]
+    assert pl.is_sat(pub, short + [0, 0, 0])
+    plonk = Plonk(pl, "BN254")
+    plonk._tau, plonk._blinding = TAU, BLIND
+    plonk.setup()
+    p1 = plonk.prove(pub, short)
+    p2 = plonk.prove(pub, N.ints_to_limbs(short))
+    p3 = plonk.prove(pub, short + [0, 0, 0])
+    assert p1.to_bytes() == p2.to_bytes() == p3.to_bytes() and plonk.verify(p1, pub)
+    opk, _ = PR.setup(g, perm, 16, cv, TAU)
+    assert p1.to_bytes() == PR.proof_bytes(PR.prove(opk, pub, short, cv, BLIND), cv)
+
+    V = FrOps(cv.r)
+    flat = V.limbs(list(range(1, 3 * 7 + 2)))           # 22 entries: columns of 8, 7, 7
+    d = V.d_from(flat)
+    for j, cnt in ((0, 8), (1, 7), (2, 7)):
+        col = DevVec(8)
+        V.d_gather(cnt, d.ptr(), 3, j, col.ptr())
+        assert (col.download(cnt) == flat[j::3]).all() and not col.download(8 - cnt, cnt).any()
 
 
 def test_unsatisfied_witnesses_are_rejected(gpu):
