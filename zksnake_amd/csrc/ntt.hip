@@ -41,10 +41,13 @@ __global__ void twiddle_kernel(uint32_t* out, Fp<P> w, uint32_t count) {
 // the 2^(m+q) elements  i = hi << (s_hi+1) | mid << s_lo | lo_blk << q | lo_in  (mid: m bits,
 // lo_in: q bits) and keeps them in LDS for all m stages.
 
+// `in` and `out` may be the same vector (every workgroup reads and writes the same index set) unless `final_pass` is
+// set: the last pass stores element i at the bit-reversed index (natural-order result), multiplied by `scale` when
+// use_scale != 0 (1/N of the inverse transform) and fully reduced -- so it must write to a different vector.
 template <class P>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(uint32_t* __restrict__ data,
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* in, uint32_t* out,
                                                                const uint32_t* __restrict__ tw, int log_n,
-                                                               int s_hi, int m, int q) {
+                                                               int s_hi, int m, int q, int final_pass, Fp<P> scale, int use_scale) {
     constexpr int N = P::N;  // register limbs (LDS is limb-major)
     constexpr int W = P::W;  // words per element in HBM
     __shared__ uint32_t lds[N][1 << NTT_TILE_LOG];
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(uint32_t* __restr
     for (int e = threadIdx.x; e < tile; e += NTT_THREADS) {
         uint32_t mid = e >> q, lo_in = e & ((1u << q) - 1);
         uint32_t idx = base | (mid << s_lo) | lo_in;
-        Fp<P> x = load_fr<P>(data + (size_t)idx * W);
+        Fp<P> x = load_fr<P>(in + (size_t)idx * W);
 #pragma unroll
         for (int l = 0; l < N; ++l) lds[l][e] = x.v[l];
     }
@@ -93,30 +96,14 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(uint32_t* __restr
         Fp<P> x;
 #pragma unroll
         for (int l = 0; l < N; ++l) x.v[l] = lds[l][e];
-        store_fr<P>(data + (size_t)idx * W, x);
+        if (final_pass) {
+            // the passes keep values semi-reduced (< 2p): the result is stored canonical, in natural order
+            if (use_scale) x = fp_mul<P>(x, scale);
+            idx = __brev(idx) >> (32 - log_n);
+            x = fp_reduce_full<P>(x);
+        }
+        store_fr<P>(out + (size_t)idx * W, x);
     }
-}
-
-// in-place bit reversal; `scale` (Montgomery form) is applied when use_scale != 0 (1/N of the iNTT)
-template <class P>
-__global__ void bitrev_scale_kernel(uint32_t* data, int log_n, Fp<P> scale, int use_scale) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (1u << log_n)) return;
-    uint32_t j = log_n == 0 ? 0 : (__brev(i) >> (32 - log_n));
-    if (i > j) return;
-    // the butterfly passes leave semi-reduced values (< 2p): this last pass stores canonical ones
-    Fp<P> a = load_fr<P>(data + (size_t)i * P::W);
-    if (use_scale) a = fp_mul<P>(a, scale);
-    a = fp_reduce_full<P>(a);
-    if (i == j) {
-        store_fr<P>(data + (size_t)i * P::W, a);
-        return;
-    }
-    Fp<P> b = load_fr<P>(data + (size_t)j * P::W);
-    if (use_scale) b = fp_mul<P>(b, scale);
-    b = fp_reduce_full<P>(b);
-    store_fr<P>(data + (size_t)i * P::W, b);
-    store_fr<P>(data + (size_t)j * P::W, a);
 }
 
 // x[i] *= g^(+-i) with g = w (table holds w^k for k < n/2; w^(n/2) = -1)
@@ -251,6 +238,7 @@ static int get_twiddles(int curve, int log_n, TwiddleSet* out, hipStream_t strea
     return ZK_OK;
 }
 
+static void free_scratch();
 static void free_twiddles() {
     std::lock_guard<std::mutex> lock(g_tw_mutex);
     for (auto& kv : g_twiddles) {
@@ -260,6 +248,43 @@ static void free_twiddles() {
     g_twiddles.clear();
 }
 
+// Scratch vector of the transform, one per stream (work on a stream is ordered, so reuse is safe); grow-only.
+struct NttScratch {
+    uint32_t* ptr = nullptr;
+    size_t bytes = 0;
+};
+static std::mutex g_scratch_mutex;
+static std::map<hipStream_t, NttScratch> g_scratch;
+
+static int get_scratch(hipStream_t stream, size_t bytes, uint32_t** out) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    NttScratch& sc = g_scratch[stream];
+    if (sc.bytes < bytes) {
+        if (sc.ptr) {
+            ZK_HIP(hipStreamSynchronize(stream));
+            (void)hipFree(sc.ptr);
+            sc.ptr = nullptr;
+            sc.bytes = 0;
+        }
+        ZK_HIP(hipMalloc(&sc.ptr, bytes));
+        sc.bytes = bytes;
+    }
+    *out = sc.ptr;
+    return ZK_OK;
+}
+
+static void free_scratch() {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    for (auto& kv : g_scratch) (void)hipFree(kv.second.ptr);
+    g_scratch.clear();
+}
+
+// Pass plan: the low min(log_n, 10) stages form the last, contiguous pass (1024 consecutive elements per workgroup);
+// the stages above are split evenly over ceil(R / 7) strided passes of m stages on 2^m rows x 2^(10-m) contiguous
+// elements -- an even split keeps the contiguous runs as long as possible (2^22: 6 + 6 + 10 with 512-byte runs).
+// Data flow: first pass d -> scratch, middle passes in place on scratch, last pass scratch -> d at bit-reversed
+// indices (+ 1/N, + canonical reduction), so no separate reordering pass.  A transform without strided stages
+// (log_n <= 10) first copies d to the scratch vector, because the permuting pass cannot run in place.
 template <class P>
 static int ntt_dev_impl(int curve, int inverse, int log_n, uint32_t* d, hipStream_t stream) {
     if (log_n < 0 || log_n > P::TWO_ADICITY || log_n > 30) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
@@ -268,31 +293,37 @@ static int ntt_dev_impl(int curve, int inverse, int log_n, uint32_t* d, hipStrea
     int rc = get_twiddles<P>(curve, log_n, &ts, stream);
     if (rc) return rc;
     const uint32_t* tw = inverse ? ts.inv : ts.fwd;
-    // stage plan: strided passes of up to (TILE_LOG - Q) stages, then one contiguous pass
-    int s = log_n - 1;
-    int last = log_n < NTT_TILE_LOG ? log_n : NTT_TILE_LOG;  // stages handled by the contiguous pass
-    while (s >= last) {
-        int remaining = s - last + 1;
-        int m = remaining < (NTT_TILE_LOG - NTT_Q) ? remaining : (NTT_TILE_LOG - NTT_Q);
-        int s_lo = s - m + 1;
-        int q = s_lo < NTT_Q ? s_lo : NTT_Q;
-        uint32_t tiles = 1u << (log_n - m - q);
-        hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(tiles), dim3(NTT_THREADS), 0, stream, d, tw, log_n, s, m, q);
-        s -= m;
-    }
-    {
-        int m = last;
-        uint32_t tiles = 1u << (log_n - m);
-        hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(tiles), dim3(NTT_THREADS), 0, stream, d, tw, log_n, m - 1, m, 0);
-    }
+    const size_t bytes = ((size_t)1 << log_n) * P::W * 4;
+    uint32_t* scratch = nullptr;
+    if ((rc = get_scratch(stream, bytes, &scratch))) return rc;
     Fp<P> scale = fp_one<P>();
     if (inverse) {
         uint32_t nn[P::W] = {0};
         nn[0] = 1u << log_n;
         scale = fp_inv<P>(fp_from_canonical<P>(nn));
     }
-    uint32_t n = 1u << log_n;
-    hipLaunchKernelGGL(bitrev_scale_kernel<P>, dim3((n + 255) / 256), dim3(256), 0, stream, d, log_n, scale, inverse ? 1 : 0);
+    const int last = log_n < NTT_TILE_LOG ? log_n : NTT_TILE_LOG;  // stages of the contiguous pass
+    const int upper = log_n - last;                                 // stages of the strided passes
+    const int max_m = NTT_TILE_LOG - NTT_Q;
+    const int n_strided = (upper + max_m - 1) / max_m;
+    const uint32_t* src = d;
+    int s = log_n - 1;
+    for (int i = 0; i < n_strided; ++i) {
+        const int m = upper / n_strided + (i < upper % n_strided ? 1 : 0);
+        const int s_lo = s - m + 1;
+        const int q = s_lo < NTT_TILE_LOG - m ? s_lo : NTT_TILE_LOG - m;
+        const uint32_t tiles = 1u << (log_n - m - q);
+        hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(tiles), dim3(NTT_THREADS), 0, stream, src, scratch, tw, log_n, s, m, q, 0, scale, 0);
+        src = scratch;
+        s -= m;
+    }
+    if (n_strided == 0) {
+        // no strided pass put the data into the scratch vector: the final pass may not run in place, so stage a copy
+        ZK_HIP(hipMemcpyAsync(scratch, d, bytes, hipMemcpyDeviceToDevice, stream));
+        src = scratch;
+    }
+    hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(1u << (log_n - last)), dim3(NTT_THREADS), 0, stream, src, d, tw, log_n, last - 1, last, 0, 1,
+                       scale, inverse ? 1 : 0);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -490,6 +521,9 @@ int zk_spmv_dev(int curve, uint64_t n_rows, const void* d_row_ptr, const void* d
 #undef CALL
 }
 
-void zk_ntt_free_cache(void) { free_twiddles(); }
+void zk_ntt_free_cache(void) {
+    free_twiddles();
+    free_scratch();
+}
 
 }  // extern "C"
