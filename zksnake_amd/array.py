@@ -20,6 +20,7 @@ class SparseArray:
         self.triplets = []
         self.triplets_map = {}
         self._csr = None
+        self._csc = None
         for i, row in enumerate(matrix):
             for j, value in enumerate(row):
                 if value != 0:
@@ -38,6 +39,7 @@ class SparseArray:
                 self.triplets_map.setdefault(row, []).append((col, value))
                 self.triplets.append((row, col, value))
         self._csr = None
+        self._csc = None
 
     def rows_map(self):
         """row -> [(col, value)] (built on demand when the matrix came from from_triplets)"""
@@ -68,3 +70,15 @@ class SparseArray:
             vals = N.ints_to_limbs([self.triplets[k][2] % p for k in order], 4)
             self._csr = (row_ptr, cols[order].astype(np.uint32), vals)
         return self._csr
+
+    def to_csc(self):
+        """the transpose in CSR form: (col_ptr uint32[n_col+1], rows uint32[nnz], vals uint64[nnz,4]) -- what
+        zk_spmv_dev needs for A^T x (the per-wire sums of Groth16.setup)"""
+        if self._csc is None or self._csr is None:
+            row_ptr, cols, vals = self.to_csr()
+            rows = np.repeat(np.arange(self.n_row, dtype=np.uint32), np.diff(row_ptr.astype(np.int64)))
+            order = np.argsort(cols, kind="stable")
+            col_ptr = np.zeros(self.n_col + 1, dtype=np.uint32)
+            np.cumsum(np.bincount(cols, minlength=self.n_col), out=col_ptr[1:])
+            self._csc = (col_ptr, np.ascontiguousarray(rows[order]), np.ascontiguousarray(vals[order]))
+        return self._csc

@@ -19,7 +19,9 @@ import numpy as np
 
 from .. import _native as N
 from ..arithmetization.r1cs import R1CS
+from ..device import DeviceBuffer
 from ..ecc import EllipticCurve, PointArray
+from ..frvec import DevVec, FrOps
 from ..polynomial import POLY_OBJECT
 from ..utils import get_random_int
 from .qap import QAP
@@ -62,30 +64,44 @@ class Groth16:
 
         n = self.qap.a.n_row
         n_wires = self.qap.a.n_col
-        mod = POLY_OBJECT[q]
-        lagrange = mod.evaluate_lagrange_coefficients(n, tau)
-
-        # per-wire QAP polynomials at tau: L_j = sum_i lagrange_i A[i][j], likewise R (B) and O (C)
-        L, R, O = [0] * n_wires, [0] * n_wires, [0] * n_wires
-        for acc, mat in ((L, self.qap.a), (R, self.qap.b), (O, self.qap.c)):
-            for row, col, value in mat.triplets:
-                acc[col] += lagrange[row] * value
-        K = [(L[j] * beta + R[j] * alpha + O[j]) % q for j in range(n_wires)]
-
-        t = mod.evaluate_vanishing_polynomial(n, tau)
-        powers = [1] * n
-        for i in range(1, n):
-            powers[i] = powers[i - 1] * tau % q
-        t_over_delta = t * inv_delta % q
-        shifted = [x * t_over_delta % q for x in powers]
-
         n_pub = self.qap.n_public
+        mod = POLY_OBJECT[q]
+        V = FrOps(q)
+        lib, cid = N.ensure_gpu(), self.E.curve.curve_id
+        # Lagrange basis at tau (host C++, one inversion), then everything per-wire on the GPU:
+        # L = A^T lag, R = B^T lag, O = C^T lag (transposed CSR SpMV), K = beta L + alpha R + O
+        d_lag = V.d_from(mod.evaluate_lagrange_coefficients(n, tau, as_limbs=True))
+        sums = []
+        for mat in (self.qap.a, self.qap.b, self.qap.c):
+            col_ptr, rows, vals = mat.to_csc()
+            out = DevVec(n_wires)
+            if len(rows):
+                bufs = [DeviceBuffer.from_numpy(x) for x in (col_ptr, rows, vals)]
+                N.check(lib.zk_spmv_dev(cid, n_wires, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, d_lag.ptr(), out.ptr(), None))
+                lib.zk_dev_synchronize()
+            sums.append(out)
+        L, R, O = sums
+        K = DevVec(n_wires, zero=False)
+        N.check(lib.zk_vec_axpby_dev(cid, n_wires, N.u64p(V.one(beta)), L.ptr(), N.u64p(V.one(alpha)), R.ptr(), None, K.ptr(), None))
+        V.d_add(n_wires, K.ptr(), O.ptr(), K.ptr())
+        k_gamma, k_delta = DevVec(max(n_pub, 1)), DevVec(max(n_wires - n_pub, 1))
+        if n_pub:
+            N.check(lib.zk_vec_axpby_dev(cid, n_pub, N.u64p(V.one(inv_gamma)), K.ptr(), None, None, None, k_gamma.ptr(), None))
+        if n_wires > n_pub:
+            N.check(lib.zk_vec_axpby_dev(cid, n_wires - n_pub, N.u64p(V.one(inv_delta)), K.ptr(n_pub), None, None, None, k_delta.ptr(), None))
+
+        # powers of tau and their t(tau)/delta multiples
+        t = mod.evaluate_vanishing_polynomial(n, tau)
+        powers = V.powers(tau, n)
+        d_pow = V.d_from(powers)
+        N.check(lib.zk_vec_axpby_dev(cid, n, N.u64p(V.one(t * inv_delta % q)), d_pow.ptr(), None, None, None, d_pow.ptr(), None))
+        shifted = d_pow.download()
+
         tau_G1 = self.E.batch_mul(G1, powers, as_array=True)
         tau_G2 = self.E.batch_mul(G2, powers, as_array=True)
         target_G1 = self.E.batch_mul(G1, shifted, as_array=True)
-        k_gamma_G1 = self.E.batch_mul(G1, [k * inv_gamma % q for k in K[:n_pub]], as_array=True)
-        k_delta = [k * inv_delta % q for k in K[n_pub:]]
-        k_delta_G1 = self.E.batch_mul(G1, k_delta, as_array=True) if k_delta else []
+        k_gamma_G1 = self.E.batch_mul(G1, k_gamma.download(n_pub), as_array=True) if n_pub else []
+        k_delta_G1 = self.E.batch_mul(G1, k_delta.download(n_wires - n_pub), as_array=True) if n_wires > n_pub else []
 
         alpha_G1, beta_G1, delta_G1 = G1 * alpha, G1 * beta, G1 * delta
         beta_G2, gamma_G2, delta_G2 = G2 * beta, G2 * gamma, G2 * delta

@@ -47,6 +47,7 @@ class QAP:
         self.a.n_row = self.b.n_row = self.c.n_row = n
         for m in (self.a, self.b, self.c):
             m._csr = None
+            m._csc = None
         self._dev = None
 
     # ---- device-resident evaluation -----------------------------------------------------------
