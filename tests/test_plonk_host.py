@@ -25,6 +25,21 @@ def test_oracle_plonk_proves_and_verifies():
         PR.prove(pk, pub, bad, cv, [1] * 11)
 
 
+def test_golden_plonk_vectors():
+    """the committed oracle proofs (tests/golden/plonk_vectors.json) are reproduced"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "plonk_vectors.json")) as f:
+        gold = json.load(f)
+    cv = pyref.BN254
+    g = gold["BN254"]["4"]
+    gates, perm, pub, priv = PR.chain_gates(4, cv.r, inp=gold["inp"])
+    assert perm == g["permutation"] and [str(v) for v in priv] == g["private"]
+    pk, _ = PR.setup(gates, perm, 4, cv, gold["tau"])
+    assert {k: pyref.compress(cv, 1, pk["tau_Q"][k]).hex() for k in "LROMC"} == g["selector_commitments"]
+    assert PR.proof_bytes(PR.prove(pk, pub, priv, cv, gold["blinding"]), cv).hex() == g["proof_bytes"]
+
+
 def test_transcript_encodings():
     from zksnake_amd.ecc import EllipticCurve
     from zksnake_amd.transcript import FiatShamirTranscript
