@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--prove-log-n", type=int, default=20)
     ap.add_argument("--precompute", action="store_true", help="plan flag ZK_MSM_PRECOMPUTE (fixed-base table 2^(cw) P_i, shared buckets)")
     ap.add_argument("--plonk-log-n", type=int, default=18, help="gates (log2) of the PlonK prove in `extra`")
+    ap.add_argument("--large-log-n", type=int, default=24, help="size (log2) of the large MSM reported in `extra` at every N")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -246,9 +247,11 @@ def main():
             }
         if not args.no_extra and world == 1:
             line["extra"] = extra_metrics(lib, torch, dev, args, bases, d_scalars, expected)
+            line["extra"].update(large_msm_metric(lib, torch, args, dev, None, 0, 1))
     if not args.no_extra and world > 1:
         # the whole prove with its MSMs window-sharded over the ranks (BASELINE metric, second half); collective on all ranks
         sharded = prove_metric(torch, args, dev if args.backend == "nccl" else None, world)
+        sharded.update(large_msm_metric(lib, torch, args, dev, gather_dev, rank, world))
         if rank == 0:
             line["extra"] = sharded
     if rank == 0:
@@ -353,6 +356,71 @@ def extra_metrics(lib, torch, dev, args, bases, d_scalars, expected):
     if not ok:
         raise SystemExit("PlonK proof does not verify")
     return out
+
+
+def large_msm_metric(lib, torch, args, dev, gather_dev, rank, world):
+    """the same MSM at 2^--large-log-n pairs (default 2^24), window-sharded when world > 1: the size at which one MSM is long
+    enough (30 ms on one GPU) for the per-rank fixed costs of the sharded form -- latency-bound bucket reduction, host tail,
+    all_gather -- to stop dominating.  The expectation (sum s_i k_i) G comes from an element-wise product and a
+    reduction on the GPU (zk_vec_op_dev, zk_poly_eval_dev at x = 1), not from the MSM code."""
+    from zksnake_amd.frvec import DevVec, FrOps
+    cid, grp, r = N.CURVE_BN254, N.G1, constant.BN254_SCALAR_FIELD
+    n = 1 << args.large_log_n
+    PW = N.point_limbs(cid, grp)
+    sc = W.splitmix64(W.SEED_MSM_SCALARS + 1, 4 * n).reshape(n, 4)
+    ks = W.splitmix64(W.SEED_MSM_BASES + 1, 4 * n).reshape(n, 4)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)   # < 2^252 < r
+    ks[:, 3] &= np.uint64((1 << 60) - 1)
+    gen = np.zeros(PW, dtype=np.uint64)
+    N.check(lib.zk_point_generator(cid, grp, N.u64p(gen)))
+    bases = np.zeros((n, PW), dtype=np.uint64)
+    N.check(lib.zk_batch_mul(cid, grp, n, N.u64p(ks), N.u64p(gen), 1, N.u64p(bases)))
+    V = FrOps(r)
+    d_s, d_k, prod = V.d_from(sc), V.d_from(ks), DevVec(n, zero=False)
+    V.d_mul(n, d_s.ptr(), d_k.ptr(), prod.ptr())
+    dot = V.d_eval(n, prod.ptr(), 1)
+    expected = np.zeros(PW, dtype=np.uint64)
+    N.check(lib.zk_point_mul(cid, grp, N.u64p(gen), N.u64p(N.ints_to_limbs([dot])), N.u64p(expected)))
+    del d_k, prod, ks
+    handle = N._u64(0)
+    N.check(lib.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, 0, args.window_bits, handle))
+    del bases
+    c_bits, nwin = N._i(0), N._i(0)
+    N.check(lib.zk_msm_plan_windows(handle, c_bits, nwin))
+    w_first, w_count = window_ranges(nwin.value, world)[rank]
+    out = np.zeros(PW, dtype=np.uint64)
+
+    def step():
+        if w_count > 0:
+            N.check(lib.zk_msm_plan_run(handle, n, d_s.ptr(), 1, w_first, w_count, N.u64p(out), None))
+        else:
+            out[:] = 0
+        return out.copy() if world == 1 else all_gather_sum(cid, grp, out, gather_dev)
+
+    res = step()
+    if not (res == expected).all():
+        raise SystemExit("large MSM does not match (sum s_i k_i) G")
+    import torch.distributed as dist
+    reps = 5
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = (time.perf_counter() - t0) / reps
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=gather_dev if gather_dev is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if not (res == expected).all():
+        raise SystemExit("large MSM result changed during the timed loop")
+    N.check(lib.zk_msm_plan_destroy(handle))
+    key = f"msm_bn254_g1_2^{args.large_log_n}" + (f"_window_sharded_x{world}" if world > 1 else "")
+    return {key: {"ms": round(dt * 1e3, 3), "Mscalar/s": round(n / dt / 1e6, 2), "windows": nwin.value}}
 
 
 def prove_metric(torch, args, shard_device, world):
