@@ -703,6 +703,7 @@ struct MsmPlan : MsmPlanBase {
     static constexpr int AW = 2 * F::LIMBS;
     static constexpr int XW = 4 * F::LIMBS;
     static constexpr int MAX_LANES = 4;
+    static constexpr uint64_t SEG_TARGET_LANES = 256ull * 1024;  // 4 waves per SIMD on 256 CUs
 
     // A run can be split over `n_lanes` groups of windows ("lanes"), each with its own stream and workspace
     // (meant to let one group's latency-bound reduction run beside the next group's accumulation; see init()
@@ -774,20 +775,8 @@ struct MsmPlan : MsmPlanBase {
             range_log = log2_u64(per);
             if ((1u << range_log) > B) range_log = c - 1;
         }
-        // segments: aim at >= 4 waves per SIMD worth of lanes
+        seg_len = pick_seg_len((uint64_t)nwin * n);
         uint64_t entries = (uint64_t)nwin * n;
-        uint64_t target = 256ull * 1024;
-        uint64_t sl = (entries + target - 1) / target;
-        if (sl < 8) sl = 8;
-        if (sl > 64) sl = 64;
-        if (pre) {
-            // shared bucket set: keep a bucket within ~12 runs so that one lane can combine it
-            uint64_t per_bucket = entries / B;
-            uint64_t want = (per_bucket + 11) / 12;
-            if (want > sl) sl = want;
-            if (sl > 1024) sl = 1024;
-        }
-        seg_len = (uint32_t)sl;
         if (entries > 0x7FFFFFFFull) return fail(ZK_ERR_ARG, "MSM too large");
         // measured at 2^20 (BN254 G1): 1 / 2 / 4 lanes -> 2.47 / 2.59 / 3.36 ms.  A full-occupancy accumulation kernel
         // leaves no wave slots for another stream's reduction kernels, so the hoped-for overlap does not happen;
@@ -830,7 +819,8 @@ struct MsmPlan : MsmPlanBase {
             const uint64_t lw = i == 0 ? (uint64_t)nwin : (uint64_t)lane_windows;
             const uint64_t keys = (pre ? 1ull : lw) * B;
             const uint64_t lane_entries = lw * n;
-            const uint64_t max_segs = lane_entries / seg_len + keys + 2;
+            // a window-range run picks its own (shorter) segments: at most SEG_TARGET_LANES of them, or entries / 8
+            const uint64_t max_segs = std::max<uint64_t>(lane_entries / seg_len, std::min<uint64_t>(lane_entries / 8, SEG_TARGET_LANES)) + keys + 8;
             ZK_HIP(hipMalloc(&l.hist, (size_t)std::max<uint64_t>(256, lw) * B * 4));  // windows x chunks <= max(256, windows)
             ZK_HIP(hipMalloc(&l.total, keys * 4));
             ZK_HIP(hipMalloc(&l.nseg, keys * 4));
@@ -875,12 +865,30 @@ struct MsmPlan : MsmPlanBase {
         return ZK_OK;
     }
 
+    // Segment length for a run over `entries` sorted entries: aim at >= 4 waves per SIMD worth of lanes (a window-range
+    // run of a sharded MSM has far fewer entries than the plan's full set; with the plan-wide length its lanes would
+    // be too few and each would walk 64 additions at lone-wave speed).
+    uint32_t pick_seg_len(uint64_t entries) const {
+        uint64_t sl = (entries + SEG_TARGET_LANES - 1) / SEG_TARGET_LANES;
+        if (sl < 8) sl = 8;
+        if (sl > 64) sl = 64;
+        if (pre) {
+            // shared bucket set: keep a bucket within ~12 runs so that one lane can combine it
+            uint64_t per_bucket = entries / B;
+            uint64_t want = (per_bucket + 11) / 12;
+            if (want > sl) sl = want;
+            if (sl > 1024) sl = 1024;
+        }
+        return (uint32_t)sl;
+    }
+
     // stages 2..7 + D2H for the windows [w_first, w_first + w_count) on stream st
     int run_lane(Lane& l, uint32_t m, uint32_t dstride, hipStream_t st, hipEvent_t after_acc) {
         const int w_first = l.w_first, w_count = l.w_count;
         const uint32_t groups = l.groups;
         const uint32_t n_keys = groups * B;
         const int nchunk = chunks_for(w_count, m);  // shadows the plan-wide value: this run's windows fill the chip
+        const uint32_t seg_len = pick_seg_len((uint64_t)w_count * m);  // shadows the plan-wide value likewise
         const uint32_t ch_len = (m + nchunk - 1) / nchunk;
         int rc;
         ZK_HIP(hipEventRecord(l.ev_begin, st));
