@@ -198,3 +198,40 @@ def test_msm_skewed_scalars(gpu):
     _known_dl_case(gpu, n, N.ints_to_limbs(ones), ones)
     same = [0xDEADBEEFCAFEBABE1234567] * n
     _known_dl_case(gpu, n, N.ints_to_limbs(same), same)
+
+
+@pytest.mark.parametrize("n", [12345, 70001, (1 << 18) + 3, (1 << 19) + 1])
+def test_msm_odd_sizes_and_window_ranges(gpu, n):
+    """sizes that are not powers of two (ragged last chunk / segment), as one run and as the three window ranges of a
+    3-rank sharded run whose partial points are summed on the host (zk_point_sum)"""
+    from zksnake_amd.parallel import sum_points, window_ranges
+    cid, grp, r = 0, 1, pyref.BN254.r
+    sc_limbs, sc_ints = W.field_stream(0xABCD + n, n, r)
+    k_limbs, k_ints = W.field_stream(0x1234 + n, n, r)
+    gen = np.zeros(8, dtype=np.uint64)
+    N.check(gpu.zk_point_generator(cid, grp, N.u64p(gen)))
+    bases = np.zeros((n, 8), dtype=np.uint64)
+    N.check(gpu.zk_batch_mul(cid, grp, n, N.u64p(k_limbs), N.u64p(gen), 1, N.u64p(bases)))
+    dot = sum(a * b for a, b in zip(sc_ints, k_ints)) % r
+    exp = np.zeros(8, dtype=np.uint64)
+    N.check(gpu.zk_point_mul(cid, grp, N.u64p(gen), N.u64p(N.ints_to_limbs([dot])), N.u64p(exp)))
+    h = N._u64(0)
+    N.check(gpu.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, 0, 0, h))
+    out = np.zeros(8, dtype=np.uint64)
+    N.check(gpu.zk_msm_plan_run(h, n, sc_limbs.ctypes.data, 0, 0, 0, N.u64p(out), None))
+    assert (out == exp).all()
+    c, nwin = N._i(0), N._i(0)
+    N.check(gpu.zk_msm_plan_windows(h, c, nwin))
+    parts = []
+    for first, count in window_ranges(nwin.value, 3):
+        part = np.zeros(8, dtype=np.uint64)
+        N.check(gpu.zk_msm_plan_run(h, n, sc_limbs.ctypes.data, 0, first, count, N.u64p(part), None))
+        parts.append(part)
+    assert (sum_points(cid, grp, parts) == exp).all()
+    # a shorter scalar vector against the same plan (multiexp's truncation rule): the first n - 5 bases only
+    m = n - 5
+    dot_m = sum(a * b for a, b in zip(sc_ints[:m], k_ints[:m])) % r
+    N.check(gpu.zk_point_mul(cid, grp, N.u64p(gen), N.u64p(N.ints_to_limbs([dot_m])), N.u64p(exp)))
+    N.check(gpu.zk_msm_plan_run(h, m, sc_limbs.ctypes.data, 0, 0, 0, N.u64p(out), None))
+    assert (out == exp).all()
+    N.check(gpu.zk_msm_plan_destroy(h))
