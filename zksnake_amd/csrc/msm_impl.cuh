@@ -306,6 +306,201 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const uint
     }
 }
 
+// ---- 2''/4''. two-level counting sort (general mode, large inputs) --------------------------------------
+// The chunked scatter above writes 4-byte references to random bucket regions of its window: every 32-byte sector
+// of `sorted` is touched by several workgroups at different times and goes to HBM as partial writes (8x write
+// amplification, the 0.2 ms of the stage).  Here the sort is split:
+//   level A  (window, chunk) workgroups partition their entries by the COARSE bin = bucket >> FINE_LOG (128 bins at
+//            c = 16): 128 write streams per workgroup, each sequential, so the lines fill up while still in L2;
+//            an entry travels as (reference, low bucket byte);
+//   level B  one workgroup per (window, coarse bin) sorts its ~n/128 entries by the low byte with LDS counters and
+//            writes them -- and the bucket offsets -- into its own contiguous slice of `sorted`.
+// Skew: when a whole wave hits one counter (many equal scalars, boolean witnesses) the increment is aggregated into
+// one atomic per wave.
+constexpr int FINE_LOG_MAX = 8;  // fine buckets per coarse bin = 2^fine_log, fine_log = 8 (n <= 2^23) or 7 (n <= 2^24):
+                                // a level-A entry is ONE word, sign | low bucket bits | point index
+
+// atomicAdd(&counter[idx], 1) returning the old value, with the wave-uniform case folded into one atomic
+__device__ __forceinline__ uint32_t lds_count(uint32_t* counter, uint32_t idx) {
+    const uint32_t first = __builtin_amdgcn_readfirstlane(idx);
+    const uint64_t act = __ballot(1);
+    const uint64_t same = __ballot(idx == first);
+    if (same == act) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+        uint32_t base = 0;
+        if (rank == 0) base = atomicAdd(&counter[first], (uint32_t)__popcll(act));
+        base = __builtin_amdgcn_readfirstlane(base);
+        return base + rank;
+    }
+    return atomicAdd(&counter[idx], 1u);
+}
+
+static __global__ __launch_bounds__(SORT_THREADS) void hist_hi_kernel(const uint16_t* __restrict__ dig, uint32_t n, uint32_t dstride, int c,
+                                                                      int w_first, int nchunk, uint32_t chunk_len, int fine_log,
+                                                                      uint32_t* __restrict__ hist) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t B = 1u << (c - 1), NB = B >> fine_log;
+    const int wl = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+    for (uint32_t b = threadIdx.x; b < NB; b += SORT_THREADS) lds[b] = 0;
+    __syncthreads();
+    uint32_t lo = chunk * chunk_len, hi = lo + chunk_len;
+    if (hi > n) hi = n;
+    const uint16_t* d = dig + (size_t)(w_first + wl) * dstride;
+    // chunk_len is a multiple of 8 and the digit rows are 16-byte aligned: eight digits per lane and load
+    for (uint32_t i = lo + threadIdx.x * 8; i < hi; i += SORT_THREADS * 8) {
+        const uint4 pk = *reinterpret_cast<const uint4*>(d + i);
+        const uint32_t wds[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int v = (int)((wds[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu) - (int)B;
+            if (i + k < hi && v != 0) (void)lds_count(lds, ((uint32_t)(v < 0 ? -v : v) - 1) >> fine_log);
+        }
+    }
+    __syncthreads();
+    uint32_t* out = hist + (size_t)blockIdx.x * NB;
+    for (uint32_t b = threadIdx.x; b < NB; b += SORT_THREADS) out[b] = lds[b];
+}
+
+// counts[(wl, chunk, bin)] -> start offsets in (window, bin, chunk) order, in place; bin_start[(wl, bin)] (+ the grand
+// total as last entry, also stored at *total_out = bucket_start[n_keys]).  One workgroup; pairs = w_count * NB <= 4096.
+static __global__ __launch_bounds__(1024) void bins_scan_kernel(uint32_t* __restrict__ hist, int w_count, int nchunk, uint32_t NB,
+                                                                uint32_t* __restrict__ bin_start, uint32_t* __restrict__ total_out) {
+    __shared__ uint32_t tot[4096];
+    const uint32_t pairs = (uint32_t)w_count * NB;
+    for (uint32_t p = threadIdx.x; p < pairs; p += blockDim.x) {
+        const uint32_t wl = p / NB, bin = p % NB;
+        uint32_t t = 0;
+        for (int ch = 0; ch < nchunk; ++ch) t += hist[((size_t)wl * nchunk + ch) * NB + bin];
+        tot[p] = t;
+    }
+    __syncthreads();
+    {
+        // exclusive scan of tot[0 .. pairs): four consecutive entries per thread, then a Hillis-Steele scan of the 1024 sums
+        __shared__ uint32_t sums[1024];
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t p = threadIdx.x * 4 + k;
+            v[k] = p < pairs ? tot[p] : 0u;
+            sum += v[k];
+        }
+        sums[threadIdx.x] = sum;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            uint32_t o = (int)threadIdx.x >= d ? sums[threadIdx.x - d] : 0u;
+            __syncthreads();
+            sums[threadIdx.x] += o;
+            __syncthreads();
+        }
+        uint32_t run = sums[threadIdx.x] - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t p = threadIdx.x * 4 + k;
+            if (p < pairs) tot[p] = run;
+            run += v[k];
+        }
+        if (threadIdx.x == 1023) {
+            bin_start[pairs] = sums[1023];
+            *total_out = sums[1023];
+        }
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < pairs; p += blockDim.x) {
+        const uint32_t wl = p / NB, bin = p % NB;
+        uint32_t run = tot[p];
+        bin_start[p] = run;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const size_t idx = ((size_t)wl * nchunk + ch) * NB + bin;
+            uint32_t t = hist[idx];
+            hist[idx] = run;
+            run += t;
+        }
+    }
+}
+
+static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_kernel(const uint16_t* __restrict__ dig, uint32_t n, uint32_t dstride, int c,
+                                                                         int w_first, int nchunk, uint32_t chunk_len, int fine_log,
+                                                                         const uint32_t* __restrict__ offsets,
+                                                                         uint32_t* __restrict__ tmp) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t B = 1u << (c - 1), NB = B >> fine_log;
+    const int index_bits = 31 - fine_log;
+    const int wl = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+    const uint32_t* off = offsets + (size_t)blockIdx.x * NB;
+    for (uint32_t b = threadIdx.x; b < NB; b += SORT_THREADS) lds[b] = off[b];
+    __syncthreads();
+    uint32_t lo = chunk * chunk_len, hi = lo + chunk_len;
+    if (hi > n) hi = n;
+    const uint16_t* d = dig + (size_t)(w_first + wl) * dstride;
+    for (uint32_t i = lo + threadIdx.x * 8; i < hi; i += SORT_THREADS * 8) {
+        const uint4 pk = *reinterpret_cast<const uint4*>(d + i);
+        const uint32_t wds[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int v = (int)((wds[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu) - (int)B;
+            if (i + k < hi && v != 0) {
+                const uint32_t b = (uint32_t)(v < 0 ? -v : v) - 1;
+                const uint32_t pos = lds_count(lds, b >> fine_log);
+                tmp[pos] = (v < 0 ? 0x80000000u : 0u) | ((b & ((1u << fine_log) - 1)) << index_bits) | (i + k);
+            }
+        }
+    }
+}
+
+constexpr int SORT_LO_THREADS = 1024;
+constexpr uint32_t SORT_LO_STAGE = 12288;  // 48 KiB of LDS: 1.5x the expected entries of a coarse bin at 2^20
+
+static __global__ __launch_bounds__(SORT_LO_THREADS) void sort_lo_kernel(const uint32_t* __restrict__ bin_start, const uint32_t* __restrict__ tmp, uint32_t B, int fine_log,
+                                                                         uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ sorted) {
+    constexpr uint32_t FINE = 1u << FINE_LOG_MAX;  // counters; the upper ones stay zero when fine_log < FINE_LOG_MAX
+    __shared__ uint32_t cnt[FINE];
+    __shared__ uint32_t stage[SORT_LO_STAGE];
+    const uint32_t NB = B >> fine_log;
+    const int index_bits = 31 - fine_log;
+    const uint32_t fine_mask = (1u << fine_log) - 1;
+    const uint32_t wl = blockIdx.x / NB, bin = blockIdx.x % NB;
+    const uint32_t s0 = bin_start[blockIdx.x], s1 = bin_start[blockIdx.x + 1];
+    for (uint32_t f = threadIdx.x; f < FINE; f += SORT_LO_THREADS) cnt[f] = 0;
+    __syncthreads();
+    // entries of a typical bin (n / 128) are kept in LDS between the counting and the placing pass
+    const bool staged = s1 - s0 <= SORT_LO_STAGE;
+    for (uint32_t e = s0 + threadIdx.x; e < s1; e += SORT_LO_THREADS) {
+        const uint32_t t = tmp[e];
+        if (staged) stage[e - s0] = t;
+        (void)lds_count(cnt, (t >> index_bits) & fine_mask);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive scan of the 256 counts by one wave: 4 per lane + a shuffle scan
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = cnt[threadIdx.x * 4 + k];
+            sum += v[k];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t o = __shfl_up(incl, d, 64);
+            if ((int)threadIdx.x >= d) incl += o;
+        }
+        uint32_t run = s0 + incl - sum;
+        uint32_t* bs = bucket_start + (size_t)wl * B + ((size_t)bin << fine_log);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t f = threadIdx.x * 4 + k;
+            cnt[f] = run;
+            if (f <= fine_mask) bs[f] = run;
+            run += v[k];
+        }
+    }
+    __syncthreads();
+    for (uint32_t e = s0 + threadIdx.x; e < s1; e += SORT_LO_THREADS) {
+        const uint32_t t = staged ? stage[e - s0] : tmp[e];
+        const uint32_t pos = lds_count(cnt, (t >> index_bits) & fine_mask);
+        sorted[pos] = (t & 0x80000000u) | (t & ((1u << index_bits) - 1));
+    }
+}
+
 // ---- 2'/4'. bucket-range partition (general mode) -----------------------------------------------------
 // One workgroup per (window, bucket range): it scans ALL digits of its window (2 B each, L2-resident, read
 // 16 B per lane) and keeps only the entries whose bucket falls in its range.  Compared with the chunked
@@ -712,6 +907,7 @@ struct MsmPlan : MsmPlanBase {
         uint32_t *hist = nullptr, *total = nullptr, *nseg = nullptr, *bstart = nullptr, *sstart = nullptr;
         uint32_t *bsums = nullptr, *grand = nullptr, *big_list = nullptr, *big_count = nullptr;
         uint32_t *sorted = nullptr, *partials = nullptr, *buckets = nullptr, *rows = nullptr, *fin = nullptr;
+        uint32_t *tmp_ref = nullptr, *bin_start = nullptr;  // two-level sort (general mode)
         hipStream_t stream = nullptr;
         hipEvent_t ev_begin = nullptr, ev_acc0 = nullptr, ev_acc1 = nullptr, ev_done = nullptr;
         int w_first = 0, w_count = 0;  // windows of the run in flight
@@ -737,7 +933,7 @@ struct MsmPlan : MsmPlanBase {
     ~MsmPlan() override {
         for (Lane& l : lanes) {
             void* bufs[] = {l.hist, l.total, l.nseg, l.bstart, l.sstart, l.bsums, l.grand, l.big_list, l.big_count,
-                            l.sorted, l.partials, l.buckets, l.rows, l.fin};
+                            l.sorted, l.partials, l.buckets, l.rows, l.fin, l.tmp_ref, l.bin_start};
             for (void* p : bufs) if (p) (void)hipFree(p);
             if (l.stream) (void)hipStreamDestroy(l.stream);
             for (hipEvent_t e : {l.ev_begin, l.ev_acc0, l.ev_acc1, l.ev_done}) if (e) (void)hipEventDestroy(e);
@@ -831,6 +1027,10 @@ struct MsmPlan : MsmPlanBase {
             ZK_HIP(hipMalloc(&l.big_list, keys * 4));
             ZK_HIP(hipMalloc(&l.big_count, 8));
             ZK_HIP(hipMalloc(&l.sorted, lane_entries * 4));
+            if (two_level_ok()) {
+                ZK_HIP(hipMalloc(&l.tmp_ref, lane_entries * 4));
+                ZK_HIP(hipMalloc(&l.bin_start, (lw * (B >> fine_log_for(n)) + 1) * 4));
+            }
             ZK_HIP(hipMalloc(&l.partials, max_segs * XW * 4));
             ZK_HIP(hipMalloc(&l.buckets, keys * XW * 4));
             ZK_HIP(hipMalloc(&l.rows, lw * (R + C) * XW * 4));
@@ -865,6 +1065,20 @@ struct MsmPlan : MsmPlanBase {
         return ZK_OK;
     }
 
+    // fine bucket bits of the two-level sort for n points: the largest of 8, 7 that leaves room for the index in a 32-bit
+    // entry, with at least four coarse bins per window and at most 4096 (window, bin) pairs (one-workgroup scan); 0 = n/a
+    int fine_log_for(uint64_t points) const {
+        for (int f = FINE_LOG_MAX; f >= FINE_LOG_MAX - 1; --f)
+            if (points <= (1ull << (31 - f)) && c - 1 >= f + 2 && (uint64_t)nwin * (B >> f) <= 4096) return f;
+        return 0;
+    }
+
+    // the two-level sort needs its own bucket set per window (general mode)
+    bool two_level_ok() const {
+        static const bool off = getenv("ZKMI_NO_TWO_LEVEL") != nullptr;
+        return !off && !pre && fine_log_for(n) > 0;
+    }
+
     // Segment length for a run over `entries` sorted entries: aim at >= 4 waves per SIMD worth of lanes (a window-range
     // run of a sharded MSM has far fewer entries than the plan's full set; with the plan-wide length its lanes would
     // be too few and each would walk 64 additions at lone-wave speed).
@@ -895,17 +1109,28 @@ struct MsmPlan : MsmPlanBase {
         // general mode, small inputs: bucket-range partition (measured faster up to 2^18); otherwise the
         // chunked counting sort with the XCD-aware scatter
         const bool ranged = !pre && m < (1u << 19);
-        if (ranged) {
+        const bool two_level = !ranged && l.tmp_ref != nullptr;
+        if (two_level) {
+            const int fl = fine_log_for(n);
+            const uint32_t NB = B >> fl;
+            const uint32_t ch8 = (ch_len + 7) & ~7u;  // the kernels read eight digits per load
+            hipLaunchKernelGGL(hist_hi_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), NB * 4, st, d_dig, m, dstride, c, w_first, nchunk, ch8, fl, l.hist);
+            hipLaunchKernelGGL(bins_scan_kernel, dim3(1), dim3(1024), 0, st, l.hist, w_count, nchunk, NB, l.bin_start, l.bstart + n_keys);
+            hipLaunchKernelGGL(scatter_hi_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), NB * 4, st, d_dig, m, dstride, c, w_first, nchunk, ch8, fl, l.hist, l.tmp_ref);
+            hipLaunchKernelGGL(sort_lo_kernel, dim3(w_count * NB), dim3(SORT_LO_THREADS), 0, st, l.bin_start, l.tmp_ref, B, fl, l.bstart, l.sorted);
+        } else if (ranged) {
             hipLaunchKernelGGL(hist_range_kernel, dim3(w_count * (B >> range_log)), dim3(SORT_THREADS), (4u << range_log), st, d_dig, m, dstride, c, w_first, range_log, l.total);
         } else {
             hipLaunchKernelGGL(hist_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), B * 4, st, d_dig, m, dstride, c, w_first, nchunk, ch_len, l.hist);
             hipLaunchKernelGGL(prefix_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, l.hist, pre ? w_count * nchunk : nchunk, B, n_keys, l.total);
         }
-        if ((rc = exclusive_scan(l, l.total, n_keys, l.bstart, st))) return rc;
+        if (!two_level && (rc = exclusive_scan(l, l.total, n_keys, l.bstart, st))) return rc;
         ZK_HIP(hipMemsetAsync(l.big_count, 0, 8, st));
         hipLaunchKernelGGL(runs_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, l.bstart, n_keys, seg_len, l.nseg, l.big_list, l.big_count);
         if ((rc = exclusive_scan(l, l.nseg, n_keys, l.sstart, st))) return rc;
-        if (ranged) {
+        if (two_level) {
+            // already sorted
+        } else if (ranged) {
             hipLaunchKernelGGL(scatter_range_kernel, dim3(w_count * (B >> range_log)), dim3(SORT_THREADS), (4u << range_log), st, d_dig, m, dstride, c, w_first, range_log, l.bstart, l.sorted);
         } else {
             const unsigned blocks = pre ? (unsigned)(w_count * nchunk) : (unsigned)(8 * ((w_count + 7) / 8) * nchunk);
