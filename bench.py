@@ -360,7 +360,7 @@ def extra_metrics(lib, torch, dev, args, bases, d_scalars, expected):
 
 def large_msm_metric(lib, torch, args, dev, gather_dev, rank, world):
     """the same MSM at 2^--large-log-n pairs (default 2^24), window-sharded when world > 1: the size at which one MSM is long
-    enough (30 ms on one GPU) for the per-rank fixed costs of the sharded form -- latency-bound bucket reduction, host tail,
+    enough (25 ms on one GPU) for the per-rank fixed costs of the sharded form -- latency-bound bucket reduction, host tail,
     all_gather -- to stop dominating.  The expectation (sum s_i k_i) G comes from an element-wise product and a
     reduction on the GPU (zk_vec_op_dev, zk_poly_eval_dev at x = 1), not from the MSM code."""
     from zksnake_amd.frvec import DevVec, FrOps
