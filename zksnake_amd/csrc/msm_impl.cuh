@@ -363,7 +363,7 @@ static __global__ __launch_bounds__(SORT_THREADS) void hist_hi_kernel(const uint
 
 // counts[(wl, chunk, bin)] -> start offsets in (window, bin, chunk) order, in place; bin_start[(wl, bin)] (+ the grand
 // total as last entry, also stored at *total_out = bucket_start[n_keys]).  One workgroup; pairs = w_count * NB <= 4096.
-static __global__ __launch_bounds__(1024) void bins_scan_kernel(uint32_t* __restrict__ hist, int w_count, int nchunk, uint32_t NB,
+static __global__ __launch_bounds__(1024) void bins_scan_kernel(uint32_t* __restrict__ hist, int w_count /* bucket sets */, int nchunk /* sub-histograms per set */, uint32_t NB,
                                                                 uint32_t* __restrict__ bin_start, uint32_t* __restrict__ total_out) {
     __shared__ uint32_t tot[4096];
     const uint32_t pairs = (uint32_t)w_count * NB;
@@ -420,6 +420,7 @@ static __global__ __launch_bounds__(1024) void bins_scan_kernel(uint32_t* __rest
 
 static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_kernel(const uint16_t* __restrict__ dig, uint32_t n, uint32_t dstride, int c,
                                                                          int w_first, int nchunk, uint32_t chunk_len, int fine_log,
+                                                                         int shared_buckets, uint32_t table_stride,
                                                                          const uint32_t* __restrict__ offsets,
                                                                          uint32_t* __restrict__ tmp) {
     extern __shared__ uint32_t lds[];
@@ -432,6 +433,8 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_kernel(const u
     uint32_t lo = chunk * chunk_len, hi = lo + chunk_len;
     if (hi > n) hi = n;
     const uint16_t* d = dig + (size_t)(w_first + wl) * dstride;
+    // with shared buckets the reference addresses the precomputed table row (w, i)
+    const uint32_t ref_base = shared_buckets ? (uint32_t)(w_first + wl) * table_stride : 0;
     for (uint32_t i = lo + threadIdx.x * 8; i < hi; i += SORT_THREADS * 8) {
         const uint4 pk = *reinterpret_cast<const uint4*>(d + i);
         const uint32_t wds[4] = {pk.x, pk.y, pk.z, pk.w};
@@ -441,7 +444,7 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_kernel(const u
             if (i + k < hi && v != 0) {
                 const uint32_t b = (uint32_t)(v < 0 ? -v : v) - 1;
                 const uint32_t pos = lds_count(lds, b >> fine_log);
-                tmp[pos] = (v < 0 ? 0x80000000u : 0u) | ((b & ((1u << fine_log) - 1)) << index_bits) | (i + k);
+                tmp[pos] = (v < 0 ? 0x80000000u : 0u) | ((b & ((1u << fine_log) - 1)) << index_bits) | (ref_base + i + k);
             }
         }
     }
@@ -1029,7 +1032,7 @@ struct MsmPlan : MsmPlanBase {
             ZK_HIP(hipMalloc(&l.sorted, lane_entries * 4));
             if (two_level_ok()) {
                 ZK_HIP(hipMalloc(&l.tmp_ref, lane_entries * 4));
-                ZK_HIP(hipMalloc(&l.bin_start, (lw * (B >> fine_log_for(n)) + 1) * 4));
+                ZK_HIP(hipMalloc(&l.bin_start, ((pre ? 1 : lw) * (B >> fine_log_for(n)) + 1) * 4));
             }
             ZK_HIP(hipMalloc(&l.partials, max_segs * XW * 4));
             ZK_HIP(hipMalloc(&l.buckets, keys * XW * 4));
@@ -1068,15 +1071,20 @@ struct MsmPlan : MsmPlanBase {
     // fine bucket bits of the two-level sort for n points: the largest of 8, 7 that leaves room for the index in a 32-bit
     // entry, with at least four coarse bins per window and at most 4096 (window, bin) pairs (one-workgroup scan); 0 = n/a
     int fine_log_for(uint64_t points) const {
-        for (int f = FINE_LOG_MAX; f >= FINE_LOG_MAX - 1; --f)
-            if (points <= (1ull << (31 - f)) && c - 1 >= f + 2 && (uint64_t)nwin * (B >> f) <= 4096) return f;
+        // fixed-base mode: ONE bucket set over references into the (window, point) table, so the references are wider
+        // and the coarse bins are shared by all windows -- more, smaller bins keep level B parallel
+        const uint64_t refs = pre ? (uint64_t)nwin * points : points;
+        const uint64_t sets = pre ? 1 : (uint64_t)nwin;
+        const int f_hi = pre ? 5 : FINE_LOG_MAX, f_lo = pre ? 4 : FINE_LOG_MAX - 1;
+        for (int f = f_hi; f >= f_lo; --f)
+            if (refs <= (1ull << (31 - f)) && c - 1 >= f + 2 && sets * (B >> f) <= 4096) return f;
         return 0;
     }
 
     // the two-level sort needs its own bucket set per window (general mode)
     bool two_level_ok() const {
         static const bool off = getenv("ZKMI_NO_TWO_LEVEL") != nullptr;
-        return !off && !pre && fine_log_for(n) > 0;
+        return !off && fine_log_for(n) > 0;
     }
 
     // Segment length for a run over `entries` sorted entries: aim at >= 4 waves per SIMD worth of lanes (a window-range
@@ -1115,9 +1123,11 @@ struct MsmPlan : MsmPlanBase {
             const uint32_t NB = B >> fl;
             const uint32_t ch8 = (ch_len + 7) & ~7u;  // the kernels read eight digits per load
             hipLaunchKernelGGL(hist_hi_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), NB * 4, st, d_dig, m, dstride, c, w_first, nchunk, ch8, fl, l.hist);
-            hipLaunchKernelGGL(bins_scan_kernel, dim3(1), dim3(1024), 0, st, l.hist, w_count, nchunk, NB, l.bin_start, l.bstart + n_keys);
-            hipLaunchKernelGGL(scatter_hi_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), NB * 4, st, d_dig, m, dstride, c, w_first, nchunk, ch8, fl, l.hist, l.tmp_ref);
-            hipLaunchKernelGGL(sort_lo_kernel, dim3(w_count * NB), dim3(SORT_LO_THREADS), 0, st, l.bin_start, l.tmp_ref, B, fl, l.bstart, l.sorted);
+            // fixed-base mode: one bucket set fed by all (window, chunk) sub-histograms; general mode: one set per window
+            const int sets = pre ? 1 : w_count, subs = pre ? w_count * nchunk : nchunk;
+            hipLaunchKernelGGL(bins_scan_kernel, dim3(1), dim3(1024), 0, st, l.hist, sets, subs, NB, l.bin_start, l.bstart + n_keys);
+            hipLaunchKernelGGL(scatter_hi_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), NB * 4, st, d_dig, m, dstride, c, w_first, nchunk, ch8, fl, pre ? 1 : 0, (uint32_t)n, l.hist, l.tmp_ref);
+            hipLaunchKernelGGL(sort_lo_kernel, dim3(sets * NB), dim3(SORT_LO_THREADS), 0, st, l.bin_start, l.tmp_ref, B, fl, l.bstart, l.sorted);
         } else if (ranged) {
             hipLaunchKernelGGL(hist_range_kernel, dim3(w_count * (B >> range_log)), dim3(SORT_THREADS), (4u << range_log), st, d_dig, m, dstride, c, w_first, range_log, l.total);
         } else {
