@@ -1,9 +1,11 @@
 """
-Fiat-Shamir transcript of the reference (python/zksnake/transcript.py:28-71): a running blake2b hash;
-a challenge is the digest, which also seeds the next hasher.  Byte encodings are the reference's, quirks
-included: an int is written big-endian on `bit_length()` BYTES (so with leading zero bytes), a point as
-its compressed encoding.  (hash_to_scalar / hash_to_curve of transcript.py:6-25 belong to the
-Bulletproofs/IPA side of the reference, outside this backend's path.)
+Fiat-Shamir transcript with the reference's behaviour (python/zksnake/transcript.py:28-71): a running blake2b hash;
+a challenge is the digest, and the digest also seeds the hasher that continues the transcript.
+
+Byte encodings are the reference's, quirks included: an int is written big-endian on `bit_length()` BYTES (so with
+leading zero bytes; 0 contributes nothing), a point as its compressed encoding, a list as the concatenation of its
+items.  (hash_to_scalar / hash_to_curve of transcript.py:6-25 belong to the Bulletproofs/IPA side of the reference,
+outside this backend's path.)
 """
 
 import hashlib
@@ -12,43 +14,39 @@ from .constant import BN254_SCALAR_FIELD
 from .ecc import ispointG1, ispointG2
 
 
+def _encode(item) -> bytes:
+    """the bytes one transcript item contributes; TypeError for anything the reference rejects"""
+    if isinstance(item, bytes):
+        return item
+    if isinstance(item, str):
+        return item.encode()
+    if isinstance(item, int):
+        return item.to_bytes(item.bit_length(), "big")
+    if ispointG1(item) or ispointG2(item):
+        return bytes(item.to_bytes())
+    if isinstance(item, list) and item:
+        head = item[0]
+        if isinstance(head, int) or ispointG1(head) or ispointG2(head):
+            return b"".join(_encode(x) for x in item)
+    raise TypeError(f"Type of {type(item)} is not supported as transcript")
+
+
 class FiatShamirTranscript:
     def __init__(self, label: bytes = b"", field=BN254_SCALAR_FIELD, alg="blake2b"):
-        self.alg = alg
-        self.label = label
-        self.hasher = hashlib.new(alg, label)
+        self.alg, self.label, self.field = alg, label, field
         self.state = []
-        self.field = field
+        self.hasher = hashlib.new(alg, label)
 
     def reset(self):
         self.hasher = hashlib.new(self.alg, self.label)
 
-    @staticmethod
-    def _int_bytes(d):
-        return int.to_bytes(d, d.bit_length(), "big")
-
     def append(self, data):
-        if isinstance(data, bytes):
-            self.hasher.update(data)
-        elif isinstance(data, str):
-            self.hasher.update(data.encode())
-        elif isinstance(data, int):
-            self.hasher.update(self._int_bytes(data))
-        elif ispointG1(data) or ispointG2(data):
-            self.hasher.update(bytes(data.to_bytes()))
-        elif data and isinstance(data, list) and isinstance(data[0], int):
-            for d in data:
-                self.hasher.update(self._int_bytes(d))
-        elif data and isinstance(data, list) and (ispointG1(data[0]) or ispointG2(data[0])):
-            for d in data:
-                self.hasher.update(bytes(d.to_bytes()))
-        else:
-            raise TypeError(f"Type of {type(data)} is not supported as transcript")
+        self.hasher.update(_encode(data))
 
     def get_challenge(self) -> bytes:
-        digest = self.hasher.digest()
-        self.hasher = hashlib.new(self.alg, digest)
-        return digest
+        out = self.hasher.digest()
+        self.hasher = hashlib.new(self.alg, out)
+        return out
 
     def get_challenge_scalar(self) -> int:
         return int.from_bytes(self.get_challenge(), "big") % self.field
