@@ -235,3 +235,17 @@ def test_msm_odd_sizes_and_window_ranges(gpu, n):
     N.check(gpu.zk_msm_plan_run(h, m, sc_limbs.ctypes.data, 0, 0, 0, N.u64p(out), None))
     assert (out == exp).all()
     N.check(gpu.zk_msm_plan_destroy(h))
+
+
+def test_one_level_sort_path_still_correct(gpu):
+    """the chunked one-level sort now only serves n > 2^24 (and the ZKMI_NO_TWO_LEVEL knob): keep it checked, in a child
+    process because the knob is read once per process"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZKMI_NO_TWO_LEVEL="1")
+    for args in (["BN254", "1", "19"], ["BN254", "1", "19", "pre"]):
+        res = subprocess.run([sys.executable, os.path.join(root, "tools", "big_msm_check.py")] + args, env=env,
+                             capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0 and "match=True" in res.stdout, res.stdout + res.stderr
