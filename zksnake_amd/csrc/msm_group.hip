@@ -18,7 +18,7 @@
 namespace zkmi {
 
 #if ZK_PART == 1
-template __global__ void accumulate_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*);
+template __global__ void accumulate_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*);
 template __global__ void precompute_kernel<ZK_GROUP>(uint32_t*, uint32_t, int, int);
 template __global__ void batch_mul_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, int, uint64_t, uint32_t*);
 template __global__ void bases_to_mont_kernel<ZK_GROUP>(const uint32_t*, uint64_t, uint32_t*);

@@ -679,12 +679,24 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_range_kernel(cons
 
 // ---- 5. accumulate (dominant kernel) ----------------------------------------------------------------
 
+// where lane t's run of bucket `key` goes: a bucket that lies within ONE segment has one run, which is the bucket sum itself
+// and is written straight to the bucket array (combine_kernel skips such buckets); otherwise the run's slot in `partials`
+template <class F>
+__device__ __forceinline__ uint32_t* run_slot(uint32_t* partials, uint32_t* buckets, const uint32_t* run_start, const uint32_t* bucket_start,
+                                              uint32_t key, uint32_t t, uint32_t seg_len) {
+    constexpr int XW = 4 * F::LIMBS;
+    const uint32_t r0 = run_start[key];
+    if (run_start[key + 1] - r0 == 1) return buckets + (size_t)key * XW;
+    return partials + (size_t)(r0 + t - bucket_start[key] / seg_len) * XW;
+}
+
 template <class G>
 __global__ __launch_bounds__(256) void accumulate_kernel(const uint32_t* __restrict__ bases,
                                                          const uint32_t* __restrict__ sorted,
                                                          const uint32_t* __restrict__ bucket_start,
                                                          const uint32_t* __restrict__ run_start, uint32_t n_keys,
-                                                         uint32_t seg_len, uint32_t* __restrict__ partials) {
+                                                         uint32_t seg_len, uint32_t* __restrict__ partials,
+                                                         uint32_t* __restrict__ buckets) {
     typedef typename G::F F;
     constexpr int AW = 2 * F::LIMBS;
     constexpr int XW = 4 * F::LIMBS;
@@ -706,7 +718,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const uint32_t* __restr
     for (uint32_t e = begin; e < end; ++e) {
         if (e == next) {
             // the bucket ends inside this segment: flush its run, move to the next non-empty bucket
-            store_xyzz<F>(partials + (size_t)(run_start[key] + t - bucket_start[key] / seg_len) * XW, acc);
+            store_xyzz<F>(run_slot<F>(partials, buckets, run_start, bucket_start, key, t, seg_len), acc);
             acc = xyzz_inf<F>();
             do {
                 ++key;
@@ -717,7 +729,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const uint32_t* __restr
         const uint32_t* src = bases + (size_t)(ref & 0x7FFFFFFFu) * AW;
         xyzz_add_affine_mem<F>(acc, src, (ref >> 31) != 0);
     }
-    store_xyzz<F>(partials + (size_t)(run_start[key] + t - bucket_start[key] / seg_len) * XW, acc);
+    store_xyzz<F>(run_slot<F>(partials, buckets, run_start, bucket_start, key, t, seg_len), acc);
 }
 
 // ---- 6. combine ---------------------------------------------------------------------------------
@@ -732,6 +744,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict
     if (key >= n_keys) return;
     uint32_t s0 = run_start[key], s1 = run_start[key + 1];
     if (s1 - s0 > COMBINE_SMALL_MAX) return;  // combine_big_kernel owns this bucket
+    if (s1 - s0 == 1) return;                 // a single run: accumulate_kernel wrote the bucket itself
     XYZZ<F> acc = xyzz_inf<F>();
     if (s1 > s0) acc = load_xyzz<F>(partials + (size_t)s0 * XW);
     for (uint32_t s = s0 + 1; s < s1; ++s) acc = xyzz_add<F>(acc, load_xyzz<F>(partials + (size_t)s * XW));
@@ -948,7 +961,7 @@ __global__ __launch_bounds__(128) void batch_mul_kernel(const uint32_t* __restri
 
 #if defined(ZK_GROUP) && (!defined(ZK_PART) || ZK_PART == 0)
 // the plan's translation unit does not instantiate the heavy kernels (see msm_group.hip)
-extern template __global__ void accumulate_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*);
+extern template __global__ void accumulate_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*);
 extern template __global__ void precompute_kernel<ZK_GROUP>(uint32_t*, uint32_t, int, int);
 extern template __global__ void batch_mul_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, int, uint64_t, uint32_t*);
 extern template __global__ void bases_to_mont_kernel<ZK_GROUP>(const uint32_t*, uint64_t, uint32_t*);
@@ -1239,7 +1252,7 @@ struct MsmPlan : MsmPlanBase {
         ZK_HIP(hipEventRecord(l.ev_acc0, st));
         // 5. accumulate
         uint64_t lanes_needed = ((uint64_t)w_count * m + seg_len - 1) / seg_len;
-        hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((lanes_needed + 255) / 256)), dim3(256), 0, st, d_bases, l.sorted, l.bstart, l.sstart, n_keys, seg_len, l.partials);
+        hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((lanes_needed + 255) / 256)), dim3(256), 0, st, d_bases, l.sorted, l.bstart, l.sstart, n_keys, seg_len, l.partials, l.buckets);
         ZK_HIP(hipEventRecord(l.ev_acc1, st));
         // 6. combine
         hipLaunchKernelGGL(combine_kernel<G>, dim3((n_keys + 255) / 256), dim3(256), 0, st, l.partials, l.sstart, n_keys, l.buckets);
