@@ -125,7 +125,7 @@ struct DigitBias {
 };
 
 template <class FrP>
-__global__ void digits_kernel(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t dstride, int c, int nwin,
+__global__ void digits_kernel(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t dstride, int c, int w_first, int w_count,
                               DigitBias bias, uint16_t* __restrict__ dig) {
     constexpr int N = FrP::W;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -148,7 +148,7 @@ __global__ void digits_kernel(const uint32_t* __restrict__ scalars, uint32_t n, 
     }
     s[N] = (uint32_t)carry + bias.v[N];
     const uint32_t mask = (1u << c) - 1;
-    for (int w = 0; w < nwin; ++w) {
+    for (int w = w_first; w < w_first + w_count; ++w) {  // only the windows of this run (a rank's share when sharded)
         int bit = w * c;
         int word = bit >> 5, off = bit & 31;
         uint64_t two = (uint64_t)s[word];
@@ -1301,7 +1301,7 @@ struct MsmPlan : MsmPlanBase {
                 int bit = w * c + (c - 1);
                 bias.v[bit >> 5] |= 1u << (bit & 31);
             }
-            hipLaunchKernelGGL(digits_kernel<FrP>, dim3((m + 255) / 256), dim3(256), 0, st, sc, m, dstride, c, nwin, bias, d_dig);
+            hipLaunchKernelGGL(digits_kernel<FrP>, dim3((m + 255) / 256), dim3(256), 0, st, sc, m, dstride, c, w_first, w_count, bias, d_dig);
             ZK_HIP(hipEventRecord(ev_digits, st));
             // split the requested windows over the lanes (big problems only: small ones are latency-bound anyway)
             int use = ((uint64_t)w_count * m >= (1ull << 22) && w_count >= 4) ? n_lanes : 1;
