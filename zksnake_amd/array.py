@@ -17,27 +17,43 @@ class SparseArray:
         self.p = p
         self.n_row = n_row
         self.n_col = n_col
-        self.triplets = []
+        self._triplets = []
+        self._columns = None  # (rows, cols, vals) as given to from_triplets, until someone asks for `triplets`
         self.triplets_map = {}
         self._csr = None
         self._csc = None
         for i, row in enumerate(matrix):
             for j, value in enumerate(row):
                 if value != 0:
-                    self.triplets.append((i, j, value))
+                    self._triplets.append((i, j, value))
 
     @classmethod
     def from_triplets(cls, rows, cols, vals, n_row, n_col, p):
-        """bulk constructor (no per-entry Python work beyond one zip)"""
+        """bulk constructor: the three columns are kept as given (lists or arrays); the reference's list of
+        (row, col, value) tuples is only built when `triplets` is read"""
         self = cls([], n_row, n_col, p)
-        self.triplets = list(zip(rows, cols, vals))
+        self._columns = (rows, cols, vals)
         return self
 
+    @property
+    def triplets(self):
+        if self._columns is not None:
+            rows, cols, vals = self._columns
+            self._triplets = list(zip((int(r) for r in rows), (int(c) for c in cols), (int(v) for v in vals)))
+            self._columns = None
+        return self._triplets
+
+    @triplets.setter
+    def triplets(self, value):
+        self._columns = None
+        self._triplets = value
+
     def append(self, triplets):
+        current = self.triplets  # materialises the tuples when the matrix came from from_triplets
         for row, col, value in triplets:
             if value != 0:
                 self.triplets_map.setdefault(row, []).append((col, value))
-                self.triplets.append((row, col, value))
+                current.append((row, col, value))
         self._csr = None
         self._csc = None
 
@@ -59,17 +75,35 @@ class SparseArray:
     def to_csr(self):
         """(row_ptr uint32[n_row+1], cols uint32[nnz], vals uint64[nnz,4]) with rows padded to n_row"""
         if self._csr is None:
-            nnz = len(self.triplets)
-            rows = np.fromiter((t[0] for t in self.triplets), dtype=np.int64, count=nnz)
-            cols = np.fromiter((t[1] for t in self.triplets), dtype=np.int64, count=nnz)
+            if self._columns is not None:
+                rows = np.asarray(self._columns[0], dtype=np.int64)
+                cols = np.asarray(self._columns[1], dtype=np.int64)
+                vals = self._value_limbs(self._columns[2])
+            else:
+                nnz = len(self._triplets)
+                rows = np.fromiter((t[0] for t in self._triplets), dtype=np.int64, count=nnz)
+                cols = np.fromiter((t[1] for t in self._triplets), dtype=np.int64, count=nnz)
+                vals = self._value_limbs([t[2] for t in self._triplets])
             order = np.argsort(rows, kind="stable")
             counts = np.bincount(rows, minlength=self.n_row)
             row_ptr = np.zeros(self.n_row + 1, dtype=np.uint32)
             np.cumsum(counts, out=row_ptr[1:])
-            p = self.p
-            vals = N.ints_to_limbs([self.triplets[k][2] % p for k in order], 4)
-            self._csr = (row_ptr, cols[order].astype(np.uint32), vals)
+            self._csr = (row_ptr, cols[order].astype(np.uint32), np.ascontiguousarray(vals[order]))
         return self._csr
+
+    def _value_limbs(self, vals):
+        """matrix values -> (nnz, 4) uint64 limbs reduced mod p; small non-negative values (the common case: +-1
+        coefficients arrive as 1 and p - 1) take a vectorised path"""
+        if isinstance(vals, np.ndarray) and vals.ndim == 2:
+            return np.ascontiguousarray(vals, dtype=np.uint64)
+        try:
+            small = np.asarray(vals, dtype=np.uint64)  # raises OverflowError for values >= 2^64 or negative
+            out = np.zeros((small.shape[0], 4), dtype=np.uint64)
+            out[:, 0] = small
+            return out
+        except (OverflowError, TypeError, ValueError):
+            p = self.p
+            return N.ints_to_limbs([int(v) % p for v in vals], 4)
 
     def to_csc(self):
         """the transpose in CSR form: (col_ptr uint32[n_col+1], rows uint32[nnz], vals uint64[nnz,4]) -- what
