@@ -68,8 +68,9 @@ int zk_point_limbs(int curve, int group); /* 64-bit limbs per affine point */
 /* ---- scalar-field vectors (polynomial_bn254 / polynomial_bls12_381 submodules) ---------- */
 
 /* fft / ifft / coset_fft / coset_ifft (src/bn254/polynomial.rs:535-585).
- * `in` holds n_in elements; the domain is next_pow2(size); the input is zero-padded (or, when
- * longer than the domain, folded modulo X^N - 1 as ark-poly does); `out` receives the whole
+ * `in` holds n_in elements; the domain is next_pow2(size); the input is zero-padded, or, when
+ * longer than the domain, truncated to it (ark-poly 0.4.2 fft_in_place/ifft_in_place resize the
+ * vector to the domain size; the crate is not vendored: parity unpinned); `out` receives the whole
  * domain in natural order. coset != 0 uses the reference's offset (= the domain generator). */
 int zk_ntt(int curve, int inverse, int coset, uint64_t n_in, const uint64_t* in, uint64_t size, uint64_t* out);
 
@@ -86,6 +87,9 @@ int zk_poly_div_vanishing(int curve, uint64_t n, uint64_t len, const uint64_t* c
 /* Device-resident forms: in place on a vector of 2^log_n canonical Fr elements. */
 int zk_ntt_dev(int curve, int inverse, int log_n, void* d_data, void* stream);
 int zk_vec_op_dev(int curve, int op, uint64_t n, const void* d_a, const void* d_b, void* d_out, void* stream);
+/* reduce every element below the modulus in place (Fr::from(BigUint), src/bn254/curve.rs:358-361): limb-array
+ * witnesses handed to the device-resident provers are only ASSUMED canonical by the kernels behind them. */
+int zk_vec_canon_dev(int curve, uint64_t n, void* d_x, void* stream);
 
 /* SparseArray.dot (python/zksnake/array.py:36-44) as a CSR sparse matrix-vector product over Fr:
  * out[row] = sum_k vals[k] * w[cols[k]] for k in [row_ptr[row], row_ptr[row+1]).  vals / w / out are

@@ -495,11 +495,11 @@ def ntt(vals, size, curve: CurveParams, inverse=False):
     r = curve.r
     n = next_pow2(size)
     if len(vals) > n:
-        # ark-poly fft() on an oversized input reduces modulo X^n - 1 first
-        folded = [0] * n
-        for i, x in enumerate(vals):
-            folded[i % n] = (folded[i % n] + x) % r
-        vals = folded
+        # the reference passes the raw slice to EvaluationDomain::fft/ifft (src/bn254/polynomial.rs:541-542, 567-568);
+        # ark-poly 0.4.2's radix-2 fft_in_place / ifft_in_place begin with `coeffs.resize(self.size(), zero)`, i.e. an
+        # over-long input is truncated (only DensePolynomial::evaluate_over_domain folds modulo X^n - 1).  ark-poly is
+        # not vendored in the reference tree: this row is parity-unpinned.
+        vals = vals[:n]
     a = [x % r for x in vals] + [0] * (n - len(vals))
     if n == 1:
         return a

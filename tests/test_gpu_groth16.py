@@ -164,20 +164,36 @@ def test_groth16_bls12_381_chain_2_10(gpu):
     assert len(proof.to_bytes()) == 192 and g.verify(proof, w[:2])
 
 
-def test_groth16_from_circom_poseidon(gpu):
-    """the reference's circom fixture end to end (tests/test_groth16.py:92-115): load tests/stub/test_poseidon.r1cs,
-    derive the witness from main.a, main.b, main.c = 1, 2, 3, prove, verify, reject a forged public output"""
+def test_groth16_from_circom(gpu):
+    """the reference's test_groth16_from_circom (tests/test_groth16.py:92-115) in the same shape: load the circom
+    fixture with its symbol file, solve from the named inputs, compile, generate the witness, setup, prove, verify"""
     import os
-    path = os.path.join(os.path.dirname(__file__), "golden", "test_poseidon.r1cs")
-    r1cs = R1CS.from_file(path)
-    w = r1cs.solve_wires({2: 1, 3: 2, 4: 3})
-    pub, priv = w[:r1cs.n_public], w[r1cs.n_public:]
+    stub = os.path.join(os.path.dirname(__file__), "golden")
+    r1cs = R1CS.from_file(os.path.join(stub, "test_poseidon.r1cs"), os.path.join(stub, "test_poseidon.sym"))
+
+    solved = r1cs.solve(
+        {
+            "main.a": 1,
+            "main.b": 2,
+            "main.c": 3,
+        },
+    )
+
+    r1cs.compile()
+
+    pub, priv = r1cs.generate_witness(solved)
+
+    groth16 = Groth16(r1cs)
+    groth16.setup()
+
+    proof = groth16.prove(pub, priv)
+
+    assert groth16.verify(proof, pub)
+    # beyond the reference's test: the witness satisfies the file's matrices, a forged public output is rejected,
+    # and the wire-index form of the solver agrees with the named form
     assert r1cs.is_sat(pub, priv)
-    g = Groth16(r1cs)
-    g.setup()
-    proof = g.prove(pub, priv)
-    assert g.verify(proof, pub)
-    assert not g.verify(proof, [pub[0], (pub[1] + 1) % r1cs.p])
+    assert not groth16.verify(proof, [pub[0], (pub[1] + 1) % r1cs.p])
+    assert r1cs.solve_wires({2: 1, 3: 2, 4: 3}) == pub + priv
 
 
 def _sharded_prove_worker(rank, world, port, curve, log_n, q):

@@ -58,6 +58,7 @@ SIGNATURES = {
     "zk_poly_div_vanishing": (_i, [_i, _u64, _u64, _u64p, _u64p, _u64p, ctypes.POINTER(_i)]),
     "zk_ntt_dev": (_i, [_i, _i, _i, _vp, _vp]),
     "zk_vec_op_dev": (_i, [_i, _i, _u64, _vp, _vp, _vp, _vp]),
+    "zk_vec_canon_dev": (_i, [_i, _u64, _vp, _vp]),
     "zk_qap_h_dev": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_i), _vp]),
     "zk_msm": (_i, [_i, _i, _u64, _u64, _u64p, _u64p, _u64p]),
     "zk_batch_mul": (_i, [_i, _i, _u64, _u64p, _u64p, _i, _u64p]),

@@ -20,6 +20,8 @@ class R1CS:
         self.curve = curve
         self.n_public = (len(cs.public_vars) + 1) if cs is not None else 1
         self.p = EllipticCurve(curve).order
+        self.wire_names = None   # from_file: wire index -> variable name (.sym labels, or out1/pub1/priv1/v1 ...)
+        self.input_wires = ()    # from_file: wires of the declared public and private inputs
 
     # ---- construction -------------------------------------------------------------------------
     @classmethod
@@ -63,13 +65,29 @@ class R1CS:
             self.C.append(c)
 
     def solve(self, inputs: dict) -> dict:
-        if self.constraint_system is None:
+        """{variable name: value} for every wire, from the declared inputs (reference r1cs.py:42-55).  Circuits loaded
+        with `from_file` are solved by constraint propagation over the matrices (`solve_wires`); as in the reference
+        only the declared inputs are read (symbolic.rs:654-663) and a missing one is an error."""
+        if self.constraint_system is not None:
+            return self.constraint_system.solve(inputs)
+        if self.wire_names is None:
             raise NotImplementedError("no symbolic constraint system attached; supply the witness directly")
-        return self.constraint_system.solve(inputs)
+        known = {}
+        for wire in self.input_wires:
+            name = self.wire_names[wire]
+            if name not in inputs:
+                raise ValueError(f"missing value for input variable {name}")
+            known[wire] = inputs[name]
+        w = self.solve_wires(known)
+        return {self.wire_names[i]: w[i] for i in range(1, len(w))}
 
     def generate_witness(self, solve_result: dict):
         if self.constraint_system is None:
-            raise NotImplementedError("no symbolic constraint system attached; supply the witness directly")
+            if self.wire_names is None:
+                raise NotImplementedError("no symbolic constraint system attached; supply the witness directly")
+            # circom wire order: [1, public outputs, public inputs, private inputs, intermediates]
+            w = [1] + [solve_result[self.wire_names[i]] % self.p for i in range(1, self.A.n_col)]
+            return w[: self.n_public], w[self.n_public:]
         w = []
         for v in self.constraint_system.get_witness_vector():
             if v == "0":
@@ -157,8 +175,11 @@ class R1CS:
     def from_file(cls, r1csfile: str, symfile: str = None, curve: str = "BN254"):
         """Load A, B, C from a circom `.r1cs` file.  Sections: 1 header, 2 constraints, 3 wire map.
         Wires: [1, public outputs, public inputs, private inputs, intermediates]; n_public counts the
-        constant wire plus the public outputs and inputs (reference r1cs.py:94-122, parser.py:10-219)."""
-        del symfile  # labels are not needed for the matrices
+        constant wire plus the public outputs and inputs (reference r1cs.py:94-122, parser.py:10-219).
+        Variable names come from the `.sym` file (rows `label,index,component,name`; only index > 0 is a wire,
+        parser.py:29-35,170-177) or, without one, are out<i>, pub<i>, priv<i>, v<i> (parser.py:178-201); they drive
+        `solve({"main.a": 1, ...})` and `generate_witness`.  The matrices are kept verbatim in circom wire order
+        (the reference re-compiles them through its symbolic system into a HashMap order; proofs do not depend on it)."""
         with open(r1csfile, "rb") as f:
             data = f.read()
         if data[:4] != b"r1cs":
@@ -194,12 +215,39 @@ class R1CS:
                     wire = int.from_bytes(body[pos:pos + 4], "little")
                     val = int.from_bytes(body[pos + 4:pos + 4 + fs], "little")
                     pos += 4 + fs
+                    if wire >= n_wires:
+                        raise IndexError(f"constraint {row} references wire {wire}, but the file declares {n_wires} wires")
                     if val:
                         mats[k].append((row, wire, val))
         for name, trip in zip("ABC", mats):
             rows, cols, vals = (list(t) for t in zip(*trip)) if trip else ([], [], [])
             setattr(self, name, SparseArray.from_triplets(rows, cols, vals, m_constraints, n_wires, self.p))
         self.n_public = 1 + n_pub_out + n_pub_in
+        first_in = 1 + n_pub_out
+        self.input_wires = tuple(range(first_in, first_in + n_pub_in + n_priv_in))
+        names = [None] * n_wires
+        if symfile:
+            import csv
+            with open(symfile, "r", encoding="utf-8") as f:
+                for rec in csv.reader(f, delimiter=","):
+                    if len(rec) != 4:
+                        continue
+                    index = int(rec[1])
+                    if 0 < index < n_wires:   # -1: optimised away; 0 is the constant wire
+                        names[index] = rec[3]
+        else:
+            layout = (("out", n_pub_out), ("pub", n_pub_in), ("priv", n_priv_in),
+                      ("v", n_wires - 1 - n_pub_out - n_pub_in - n_priv_in))
+            wire = 1
+            for prefix, count in layout:
+                for k in range(count):
+                    names[wire] = f"{prefix}{k + 1}"
+                    wire += 1
+        missing = [i for i in range(1, n_wires) if names[i] is None]
+        if missing:
+            raise ValueError(f"the symbol file names no variable for wires {missing[:8]}{'...' if len(missing) > 8 else ''}")
+        names[0] = "0"
+        self.wire_names = names
         self.header = dict(n_wires=n_wires, n_pub_out=n_pub_out, n_pub_in=n_pub_in, n_priv_in=n_priv_in,
                            m_constraints=m_constraints, prime=prime)
         return self

@@ -84,6 +84,12 @@ class SparseArray:
                 rows = np.fromiter((t[0] for t in self._triplets), dtype=np.int64, count=nnz)
                 cols = np.fromiter((t[1] for t in self._triplets), dtype=np.int64, count=nnz)
                 vals = self._value_limbs([t[2] for t in self._triplets])
+            # the GPU SpMV reads w[cols[k]] unchecked: reject out-of-range indices here, as the reference's dot() does
+            # with an IndexError (array.py:36-44)
+            if rows.size and (int(rows.min()) < 0 or int(rows.max()) >= self.n_row):
+                raise IndexError(f"row index out of range for a matrix with {self.n_row} rows")
+            if cols.size and (int(cols.min()) < 0 or int(cols.max()) >= self.n_col):
+                raise IndexError(f"column index out of range for a matrix with {self.n_col} columns")
             order = np.argsort(rows, kind="stable")
             counts = np.bincount(rows, minlength=self.n_row)
             row_ptr = np.zeros(self.n_row + 1, dtype=np.uint32)
@@ -96,8 +102,19 @@ class SparseArray:
         coefficients arrive as 1 and p - 1) take a vectorised path"""
         if isinstance(vals, np.ndarray) and vals.ndim == 2:
             return np.ascontiguousarray(vals, dtype=np.uint64)
+        if isinstance(vals, np.ndarray):
+            # numpy casts silently: a signed -1 would wrap to 2^64 - 1 instead of p - 1, a float would truncate.
+            # Only unsigned integers, or signed ones that are all non-negative, take the vectorised path.
+            fast = vals.dtype.kind == "u" or (vals.dtype.kind == "i" and (vals.size == 0 or int(vals.min()) >= 0))
+            if vals.dtype.kind not in "uiO":
+                raise TypeError(f"matrix values must be integers, got dtype {vals.dtype}")
+            if fast:
+                out = np.zeros((vals.shape[0], 4), dtype=np.uint64)
+                out[:, 0] = vals.astype(np.uint64)
+                return out
+            return N.ints_to_limbs([int(v) % self.p for v in vals], 4)
         try:
-            small = np.asarray(vals, dtype=np.uint64)  # raises OverflowError for values >= 2^64 or negative
+            small = np.asarray(vals, dtype=np.uint64)  # Python ints: raises OverflowError for values >= 2^64 or negative
             out = np.zeros((small.shape[0], 4), dtype=np.uint64)
             out[:, 0] = small
             return out

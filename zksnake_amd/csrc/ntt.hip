@@ -355,22 +355,18 @@ static int ntt_host_impl(int curve, int inverse, int coset, uint64_t n_in, const
     if (log_n > P::TWO_ADICITY || log_n > 30) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
     const size_t eb = P::W * 4;
     uint32_t* d = nullptr;
-    uint64_t alloc = n_in > n ? n_in : n;
+    // An input longer than the domain is TRUNCATED to the domain size: the reference hands the raw slice to
+    // EvaluationDomain::fft / ifft (polynomial.rs:541-542,567-568), whose radix-2 fft_in_place / ifft_in_place start with
+    // `coeffs.resize(self.size(), zero)` [ark-poly 0.4.2, not vendored: parity unpinned, see DESIGN.md section 2]; only
+    // DensePolynomial::evaluate_over_domain folds modulo X^n - 1, and the reference does not call it on this path.
+    if (n_in > n) n_in = n;
+    const uint64_t alloc = n;
     ZK_HIP(hipMalloc(&d, alloc * eb));
     int rc = ZK_OK;
     do {
         if (hipMemset(d, 0, alloc * eb) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemset failed"); break; }
         if (n_in && hipMemcpy(d, in, n_in * eb, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy H2D failed"); break; }
         hipLaunchKernelGGL(canon_kernel<P>, dim3((unsigned)((alloc + 255) / 256)), dim3(256), 0, 0, alloc, d);
-        if (n_in > n) {
-            // fold modulo X^n - 1: x[i] += x[i + k n]
-            for (uint64_t off = n; off < n_in; off += n) {
-                uint64_t cnt = n_in - off < n ? n_in - off : n;
-                rc = vec_op_dev_impl<P>(1, cnt, d, d + off * P::W, d, 0);
-                if (rc) break;
-            }
-            if (rc) break;
-        }
         if (coset && !inverse) { rc = coset_scale_impl<P>(curve, 0, log_n, d, 0); if (rc) break; }
         rc = ntt_dev_impl<P>(curve, inverse, log_n, d, 0);
         if (rc) break;
@@ -516,6 +512,19 @@ int zk_spmv_dev(int curve, uint64_t n_rows, const void* d_row_ptr, const void* d
                            (const uint32_t*)d_w, (uint32_t*)d_out);                                               \
         ZK_HIP(hipGetLastError());                                                                               \
         return ZK_OK;                                                                                            \
+    }
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_vec_canon_dev(int curve, uint64_t n, void* d_x, void* stream) {
+    if (n == 0) return ZK_OK;
+#define CALL(P)                                                                                                       \
+    {                                                                                                                 \
+        hipLaunchKernelGGL(canon_kernel<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n,  \
+                           (uint32_t*)d_x);                                                                           \
+        ZK_HIP(hipGetLastError());                                                                                    \
+        return ZK_OK;                                                                                                 \
     }
     ZK_DISPATCH_FR(curve, CALL);
 #undef CALL

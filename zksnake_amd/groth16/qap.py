@@ -98,6 +98,9 @@ class QAP:
             if part.shape[0]:
                 ws["w"].upload(part, offset=off)
             off += part.nbytes
+        if any(isinstance(x, np.ndarray) for x in (witness if isinstance(witness, tuple) else (witness,))):
+            # int lists were reduced mod r on the host (Fr::from); limb arrays are reduced here, one cheap pass
+            N.check(lib.zk_vec_canon_dev(cid, self.a.n_col, ws["w"].ptr, None))
         for (rp, cl, vl), dst in zip(self._device_matrices(), (ws["a"], ws["b"], ws["c"])):
             N.check(lib.zk_spmv_dev(cid, n, rp.ptr, cl.ptr, vl.ptr, ws["w"].ptr, dst.ptr, None))
         ok = N._i(0)

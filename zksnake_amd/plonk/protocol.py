@@ -209,10 +209,15 @@ class Plonk:
         # the flat witness goes up once and is de-interleaved on the GPU into the three n-domain columns (gate check, grand
         # product); the coefficient vectors are m entries long so the same buffers later feed the coset transforms
         wit_d = V.d_from(wit, 3 * rows)
+        if isinstance(private_witness, np.ndarray):  # int lists are reduced by V.limbs; limb arrays here (Fr::from)
+            N.check(N.load().zk_vec_canon_dev(V.cid, 3 * rows, wit_d.ptr(), None))
         col_d = []
         for j in range(3):
             col = DevVec(n, zero=rows < n)
-            V.d_gather((wit.shape[0] - j + 2) // 3, wit_d.ptr(), 3, j, col.ptr())
+            # `rows` entries for EVERY column: wit_d is zero-padded to 3 * rows, so a witness whose length is not a
+            # multiple of three gets zeros in the missing b / c slots of its last row, as the reference pads a, b, c
+            # (plonk/protocol.py:167-169) -- never stale data of a pooled buffer
+            V.d_gather(rows, wit_d.ptr(), 3, j, col.ptr())
             col_d.append(col)
         pi_d = DevVec(n)
         for k, v in public_witness.items():
