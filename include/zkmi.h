@@ -60,6 +60,11 @@ int zk_dev_upload(void* d_dst, const void* h_src, uint64_t bytes);
 int zk_dev_download(void* h_dst, const void* d_src, uint64_t bytes);
 int zk_dev_memset(void* d_dst, int value, uint64_t bytes);
 int zk_dev_synchronize(void);
+/* HIP streams for callers that keep several device-resident pipelines in flight (the Python host has no HIP binding
+ * of its own): non-blocking with respect to the default stream; high_priority != 0 asks for the top priority level. */
+int zk_stream_create(int high_priority, void** stream);
+int zk_stream_destroy(void* stream);
+int zk_stream_synchronize(void* stream);
 
 /* limb counts, so bindings do not hard-code them */
 int zk_fq_limbs(int curve);         /* 64-bit limbs per base-field element: 4 / 6 */
@@ -123,8 +128,16 @@ int zk_batch_mul(int curve, int group, uint64_t n, const uint64_t* scalars, cons
  * points.  flags: bit0 = precompute the per-window multiples 2^(c*w) * P_i so that every window
  * shares one bucket set (uses n * windows * point bytes of HBM); window_bits 0 = automatic. */
 #define ZK_MSM_PRECOMPUTE 1
+#define ZK_MSM_HIGH_PRIORITY 2 /* the plan's own stream (ZK_STREAM_PLAN) gets the top stream priority */
 int zk_msm_plan_create(int curve, int group, uint64_t n, const void* bases, int bases_on_device, int flags,
                        int window_bits, uint64_t* handle);
+/* The same for a rank of a window-sharded MSM that will only ever run the windows
+ * [window_first, window_first + window_count) (window_count 0 = all): the fixed-base table and the
+ * workspace are sized for that range only -- 1/8 of the memory and of the table build on 8 ranks.
+ * Runs outside the range fail with ZK_ERR_ARG.  Call zk_msm_plan_windows on a throw-away
+ * n = 1 plan (or compute ceil((bits + 1) / c)) to learn the window count first. */
+int zk_msm_plan_create_range(int curve, int group, uint64_t n, const void* bases, int bases_on_device, int flags,
+                             int window_bits, int window_first, int window_count, uint64_t* handle);
 int zk_msm_plan_destroy(uint64_t handle);
 /* scalars: n_scalars <= plan n canonical Fr elements (host or device per `scalars_on_device`); the
  * first n_scalars bases are used (ecc.py:118-119 truncation rule).  Result: one affine point in host

@@ -196,21 +196,40 @@ def test_groth16_from_circom(gpu):
     assert r1cs.solve_wires({2: 1, 3: 2, 4: 3}) == pub + priv
 
 
-def _sharded_prove_worker(rank, world, port, curve, log_n, q):
-    """one rank of a window-sharded prove; all ranks share the box's single GPU and exchange over gloo"""
+def _sharded_prove_worker(rank, world, port, curve, log_n, q, backend="gloo"):
+    """one rank of a window-sharded prove; with gloo all ranks share the box's single GPU, with nccl (= RCCL) every rank
+    owns GPU `rank` and the partial points are gathered on the device"""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = None
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dev = torch.device("cuda", rank)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         cv = pyref.curve_by_name(curve)
         n = 1 << log_n
         A, B, C, w, n_col = W.chain_circuit(n, cv.r)
+        if backend == "nccl":
+            # the exchange primitives of zksnake_amd/parallel.py through RCCL, on device tensors
+            from zksnake_amd.parallel import all_gather_limbs, all_gather_sum
+            mine = np.arange(16, dtype=np.uint64) + np.uint64(100 * rank)
+            got = all_gather_limbs(mine, dev)
+            assert got.shape == (world, 16) and (got[rank] == mine).all()
+            E = EllipticCurve(curve)
+            from zksnake_amd._algebra import _points_to_limbs
+            part = _points_to_limbs([E.G1() * (rank + 5)], E.curve.curve_id, 1)[0]
+            total = all_gather_sum(E.curve.curve_id, 1, part, dev)
+            assert (total == _points_to_limbs([E.G1() * sum(r + 5 for r in range(world))], E.curve.curve_id, 1)[0]).all()
         g = Groth16(R1CS.from_triplets(A, B, C, n, n_col, 2, curve), curve)
         g._toxic, g._blinding = TOXIC, BLIND
         g.setup()
-        g.shard_over_ranks()
+        g.shard_over_ranks(dev)
         proof = g.prove(N.ints_to_limbs(w[:2]), N.ints_to_limbs(w[2:]))
         g._blinding = None  # drawn on rank 0 and broadcast: all ranks still agree
         proof_r = g.prove(w[:2], w[2:])
@@ -246,3 +265,27 @@ def test_window_sharded_prove_two_and_three_ranks(gpu, curve, world):
     assert [r[0] for r in results] == list(range(world))
     assert all(r[1] == exp for r in results), "sharded proof differs from the closed form"
     assert all(r[2] for r in results) and len({r[3] for r in results}) == 1
+
+
+def test_rccl_code_path_world_size_one(gpu):
+    """the `nccl` (= RCCL) branch of the sharded path on real hardware: a one-rank group on the box's GPU runs
+    all_gather_limbs / all_gather_sum on device tensors, Groth16.shard_over_ranks(device) + prove (pinned and
+    broadcast blinding), so that `bench.py --gpus 8` is not the first time RCCL sees this code (RCCL wants one GPU
+    per rank: more ranks are covered over gloo above).  Child process: the process group must not leak into pytest."""
+    import socket
+    import torch.multiprocessing as mp
+    curve, log_n = "BN254", 10
+    cv = pyref.curve_by_name(curve)
+    n = 1 << log_n
+    A, B, C, w, n_col = W.chain_circuit(n, cv.r)
+    exp = _oracle_proof_bytes((list(zip(*A)), list(zip(*B)), list(zip(*C)), n, n_col, 2, w), cv).hex()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_sharded_prove_worker, args=(0, 1, port, curve, log_n, q, "nccl"))
+    p.start()
+    rank, proof_hex, verified, _ = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0 and rank == 0 and proof_hex == exp and verified

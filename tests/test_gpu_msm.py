@@ -161,6 +161,65 @@ def test_batch_mul(gpu, name, cid, grp):
     assert (out2 == corc.batch_mul(cid, grp, sc, exp)).all()
 
 
+@pytest.mark.parametrize("name,cid", CURVES)
+@pytest.mark.parametrize("grp", [1, 2])
+def test_batch_mul_fixed_base_table(gpu, name, cid, grp):
+    """one base, many scalars (what Groth16.setup does, protocol.py:81-97): the fixed-base path (16 signed 16-bit digits
+    against a table of d * 2^(16 j) * G, batched inversion) against the oracle's double-and-add, edge scalars included;
+    a second base must rebuild the cached table"""
+    cv = pyref.curve_by_name(name)
+    n = 2500
+    gen = generator_limbs(gpu, cid, grp)
+    vals, _ = rand_scalars(n, cv.r, 81 + grp)
+    vals[:8] = [0, 1, cv.r - 1, 2, cv.r + 3, 1 << 15, (1 << 16) - 1, (1 << 255) - 1]   # >= r reduces like Fr::from
+    vals[8] = sum(1 << (16 * j + 15) for j in range(15))                               # every digit at the carry boundary
+    sc = N.ints_to_limbs(vals, 4)
+    out = np.zeros((n, N.point_limbs(cid, grp)), dtype=np.uint64)
+    N.check(gpu.zk_batch_mul(cid, grp, n, N.u64p(sc), N.u64p(gen), 1, N.u64p(out)))
+    exp = corc.batch_mul(cid, grp, sc, gen)
+    assert (out == exp).all()
+    other = exp[5].copy()                                                              # another base: 7-ish * G
+    N.check(gpu.zk_batch_mul(cid, grp, n, N.u64p(sc), N.u64p(other), 1, N.u64p(out)))
+    assert (out == corc.batch_mul(cid, grp, sc, other)).all()
+    inf = np.zeros_like(gen)                                                           # the point at infinity as the base
+    N.check(gpu.zk_batch_mul(cid, grp, n, N.u64p(sc), N.u64p(inf), 1, N.u64p(out)))
+    assert not out.any()
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_plan_for_a_window_range(gpu, flags):
+    """zk_msm_plan_create_range: a rank's plan holds only its windows (table rows, workspace); the partial points of the
+    three ranks add up to the full MSM and a run outside the range is refused"""
+    from zksnake_amd.parallel import sum_points, window_ranges
+    cid, grp, cv = 0, 1, pyref.BN254
+    n = 1500
+    _, bases = oracle_bases(cid, grp, n, 95)
+    _, sc = rand_scalars(n, cv.r, 96)
+    exp = corc.msm(cid, grp, sc, bases, threads=8)
+    nwin = (254 + 1 + 12 - 1) // 12
+    parts = []
+    for first, count in window_ranges(nwin, 3):
+        h = N._u64(0)
+        N.check(gpu.zk_msm_plan_create_range(cid, grp, n, bases.ctypes.data, 0, flags, 12, first, count, h))
+        try:
+            part = np.zeros(8, dtype=np.uint64)
+            N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, 0, 0, N.u64p(part), None))      # 0, 0 = the plan's range
+            again = np.zeros(8, dtype=np.uint64)
+            N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, first, count, N.u64p(again), None))
+            assert (part == again).all()
+            if count > 1:
+                a, b = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+                N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, first, 1, N.u64p(a), None))
+                N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, first + 1, count - 1, N.u64p(b), None))
+                assert (sum_points(cid, grp, [a, b]) == part).all()
+            outside = first - 1 if first > 0 else first + count
+            assert gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, outside, 1, N.u64p(again), None) == N.ZK_ERR_ARG
+            parts.append(part)
+        finally:
+            N.check(gpu.zk_msm_plan_destroy(h))
+    assert (sum_points(cid, grp, parts) == exp).all()
+
+
 def _known_dl_case(gpu, n, scalars_limbs, scalar_ints, cid=0, grp=1):
     r = (pyref.BN254 if cid == 0 else pyref.BLS12_381).r
     k_limbs, k_ints = W.field_stream(W.SEED_MSM_BASES, n, r)

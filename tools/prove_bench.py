@@ -49,7 +49,7 @@ def main():
         times.append(time.perf_counter() - s)
     out = {"curve": args.curve, "log_n": args.log_n, "build_s": round(t1 - t0, 2), "setup_s": round(t2 - t1, 2),
            "prove_first_ms": round(times[0] * 1e3, 2), "prove_ms": round(min(times[1:]) * 1e3, 2),
-           "prove_ms_all": [round(t * 1e3, 2) for t in times[1:]], "verifies": bool(g.verify(proof, w[:2])),
+           "prove_ms_all": [round(t * 1e3, 2) for t in times[1:]], "timeline_ms": {k: round(v, 3) for k, v in g.last_timings.items()}, "verifies": bool(g.verify(proof, w[:2])),
            "proof_hex": proof.to_bytes().hex()}
     if args.check:
         from oracle import pyref

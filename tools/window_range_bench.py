@@ -28,7 +28,7 @@ N.check(lib.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, 0, 0, h))
 d = DeviceBuffer.from_numpy(sc)
 out = np.zeros(8, dtype=np.uint64)
 tm = (N.ctypes.c_float * 5)()
-for wc in (16, 8, 4, 2, 1):
+for wc in ([int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (16, 8, 4, 2, 1)):
     for _ in range(3):
         N.check(lib.zk_msm_plan_run(h, n, d.ptr, 1, 0, wc, N.u64p(out), None))
     t0 = time.perf_counter()

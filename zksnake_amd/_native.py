@@ -29,6 +29,7 @@ G1 = 1
 G2 = 2
 
 MSM_PRECOMPUTE = 1
+MSM_HIGH_PRIORITY = 2
 STREAM_PLAN = ctypes.c_void_p(-1)  # ZK_STREAM_PLAN: the plan's own stream
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -50,6 +51,9 @@ SIGNATURES = {
     "zk_dev_download": (_i, [_vp, _vp, _u64]),
     "zk_dev_memset": (_i, [_vp, _i, _u64]),
     "zk_dev_synchronize": (_i, []),
+    "zk_stream_create": (_i, [_i, ctypes.POINTER(_vp)]),
+    "zk_stream_destroy": (_i, [_vp]),
+    "zk_stream_synchronize": (_i, [_vp]),
     "zk_spmv_dev": (_i, [_i, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "zk_fq_limbs": (_i, [_i]),
     "zk_point_limbs": (_i, [_i, _i]),
@@ -63,6 +67,7 @@ SIGNATURES = {
     "zk_msm": (_i, [_i, _i, _u64, _u64, _u64p, _u64p, _u64p]),
     "zk_batch_mul": (_i, [_i, _i, _u64, _u64p, _u64p, _i, _u64p]),
     "zk_msm_plan_create": (_i, [_i, _i, _u64, _vp, _i, _i, _i, _u64p]),
+    "zk_msm_plan_create_range": (_i, [_i, _i, _u64, _vp, _i, _i, _i, _i, _i, _u64p]),
     "zk_msm_plan_destroy": (_i, [_u64]),
     "zk_msm_plan_run": (_i, [_u64, _u64, _vp, _i, _i, _i, _u64p, _vp]),
     "zk_msm_plan_enqueue": (_i, [_u64, _u64, _vp, _i, _i, _i, _vp]),

@@ -390,6 +390,24 @@ int zk_dev_synchronize(void) {
     ZK_HIP(hipDeviceSynchronize());
     return ZK_OK;
 }
+int zk_stream_create(int high_priority, void** stream) {
+    // a stream that does not synchronise with the legacy default stream, so that work given to it overlaps with the
+    // MSM plans' own streams and with default-stream work
+    int lo = 0, hi = 0;
+    ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // numerically lower = higher priority
+    hipStream_t st = nullptr;
+    ZK_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, high_priority ? hi : lo));
+    *stream = (void*)st;
+    return ZK_OK;
+}
+int zk_stream_destroy(void* stream) {
+    if (stream) ZK_HIP(hipStreamDestroy((hipStream_t)stream));
+    return ZK_OK;
+}
+int zk_stream_synchronize(void* stream) {
+    ZK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return ZK_OK;
+}
 
 const char* zk_last_error(void) { return last_error_ref().c_str(); }
 const char* zk_version(void) { return "zkmi 0.1 (gfx950)"; }

@@ -13,8 +13,8 @@ static uint64_t g_next_plan = 1;
 
 
 static int plan_create_dispatch(int curve, int group, uint64_t n, const void* bases, int on_device, int flags,
-                                int window_bits, MsmPlanBase** out) {
-#define CALL(G) return msm_plan_create_##G(n, bases, on_device, flags, window_bits, out)
+                                int window_bits, int window_first, int window_count, MsmPlanBase** out) {
+#define CALL(G) return msm_plan_create_##G(n, bases, on_device, flags, window_bits, window_first, window_count, out)
     if (curve == ZK_CURVE_BN254 && group == ZK_G1) { CALL(Bn254G1); }
     if (curve == ZK_CURVE_BN254 && group == ZK_G2) { CALL(Bn254G2); }
     if (curve == ZK_CURVE_BLS12_381 && group == ZK_G1) { CALL(Bls381G1); }
@@ -32,8 +32,13 @@ extern "C" {
 
 int zk_msm_plan_create(int curve, int group, uint64_t n, const void* bases, int bases_on_device, int flags,
                        int window_bits, uint64_t* handle) {
+    return zk_msm_plan_create_range(curve, group, n, bases, bases_on_device, flags, window_bits, 0, 0, handle);
+}
+
+int zk_msm_plan_create_range(int curve, int group, uint64_t n, const void* bases, int bases_on_device, int flags,
+                             int window_bits, int window_first, int window_count, uint64_t* handle) {
     MsmPlanBase* p = nullptr;
-    int rc = plan_create_dispatch(curve, group, n, bases, bases_on_device, flags, window_bits, &p);
+    int rc = plan_create_dispatch(curve, group, n, bases, bases_on_device, flags, window_bits, window_first, window_count, &p);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(g_plan_mutex);
     *handle = g_next_plan++;
@@ -127,6 +132,10 @@ void zk_msm_free_all(void) {
     std::lock_guard<std::mutex> lock(g_plan_mutex);
     for (auto& kv : g_plans) delete kv.second;
     g_plans.clear();
+    msm_fixed_table_free_Bn254G1();
+    msm_fixed_table_free_Bn254G2();
+    msm_fixed_table_free_Bls381G1();
+    msm_fixed_table_free_Bls381G2();
 }
 
 }  // extern "C"

@@ -2,8 +2,9 @@
 // Compiled by the Makefile once per group and per part, so that the heavy kernels (field products inlined:
 // a BLS12-381 G2 mixed addition is ~14k instructions) build in parallel:
 //   ZK_PART 0: the plan (host code) and the small kernels; the heavy kernels are only declared (extern template)
-//   ZK_PART 1: accumulate / precompute / batch_mul / bases_to_mont kernels
+//   ZK_PART 1: accumulate / bases_to_mont kernels
 //   ZK_PART 2: combine (3 tiers) / strided_sum / weighted_sum kernels
+//   ZK_PART 3: setup-side kernels (batched normalisation, fixed-base table rows, batch scalar multiplication)
 #include "msm_impl.cuh"
 
 #ifndef ZK_GROUP
@@ -19,21 +20,19 @@ namespace zkmi {
 
 #if ZK_PART == 1
 template __global__ void accumulate_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*);
-template __global__ void precompute_kernel<ZK_GROUP>(uint32_t*, uint32_t, int, int);
-template __global__ void batch_mul_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, int, uint64_t, uint32_t*);
 template __global__ void bases_to_mont_kernel<ZK_GROUP>(const uint32_t*, uint64_t, uint32_t*);
 #elif ZK_PART == 2
-template __global__ void combine_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, uint32_t, uint32_t*);
-template __global__ void combine_wave_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*);
-template __global__ void combine_big_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const uint32_t*, uint32_t*);
+template __global__ void combine_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*);
 template __global__ void strided_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t*, SumJob, SumJob, uint32_t);
 template __global__ void weighted_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t, uint32_t, const uint32_t*, uint32_t, uint32_t*);
+#elif ZK_PART == 3
+ZK_SETUP_INSTANTIATE(ZK_GROUP)
 #else
 
 int ZK_CAT(msm_plan_create_, ZK_GROUP)(uint64_t n, const void* bases, int on_device, int flags, int window_bits,
-                                       MsmPlanBase** out) {
+                                       int window_first, int window_count, MsmPlanBase** out) {
     MsmPlan<ZK_GROUP>* p = new MsmPlan<ZK_GROUP>();
-    int rc = p->init(n, bases, on_device, flags, window_bits);
+    int rc = p->init(n, bases, on_device, flags, window_bits, window_first, window_count);
     if (rc) {
         delete p;
         return rc;
@@ -41,6 +40,8 @@ int ZK_CAT(msm_plan_create_, ZK_GROUP)(uint64_t n, const void* bases, int on_dev
     *out = p;
     return ZK_OK;
 }
+
+void ZK_CAT(msm_fixed_table_free_, ZK_GROUP)() { FixedTable<ZK_GROUP>::get().release(); }
 
 int ZK_CAT(msm_batch_mul_, ZK_GROUP)(uint64_t n, const uint64_t* scalars, const uint64_t* bases, int broadcast,
                                      uint64_t* out) {

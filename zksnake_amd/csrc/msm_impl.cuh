@@ -28,6 +28,8 @@
 #include <vector>
 #include "common.cuh"
 #include "msm_plan.h"
+#include "pair.cuh"
+#include "setup_impl.cuh"
 
 namespace zkmi {
 
@@ -126,9 +128,10 @@ struct DigitBias {
 
 template <class FrP>
 __global__ void digits_kernel(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t dstride, int c, int w_first, int w_count,
-                              DigitBias bias, uint16_t* __restrict__ dig) {
+                              DigitBias bias, uint16_t* __restrict__ dig, uint32_t* __restrict__ big_count) {
     constexpr int N = FrP::W;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) big_count[0] = big_count[1] = 0;  // consumed by runs_scan_block_kernel later in the same stream
     if (i >= n) return;
     uint32_t s[N + 1];
     load_words<N>(s, scalars + (size_t)i * N);
@@ -205,20 +208,6 @@ static __global__ void prefix_kernel(uint32_t* __restrict__ hist, int group_size
 // The sorted entry list is cut into uniform segments of seg_len entries (one lane each), whatever the bucket
 // sizes are.  A "run" is the part of one bucket inside one segment; bucket `key` owns
 //   nruns = 1 + (last_entry / seg_len) - (first_entry / seg_len)   consecutive partial slots.
-static __global__ void runs_kernel(const uint32_t* __restrict__ bucket_start, uint32_t n_keys, uint32_t seg_len,
-                                   uint32_t* __restrict__ nruns, uint32_t* __restrict__ big_list,
-                                   uint32_t* __restrict__ big_count) {
-    // big_list is filled from the front with wave-tier buckets and from the back with workgroup-tier buckets;
-    // big_count[0] / big_count[1] are the two lengths
-    uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
-    if (key >= n_keys) return;
-    uint32_t s0 = bucket_start[key], s1 = bucket_start[key + 1];
-    uint32_t r = s1 > s0 ? 1 + (s1 - 1) / seg_len - s0 / seg_len : 0;
-    nruns[key] = r;
-    if (r > COMBINE_WAVE_MAX) big_list[n_keys - 1 - atomicAdd(big_count + 1, 1u)] = key;
-    else if (r > COMBINE_SMALL_MAX) big_list[atomicAdd(big_count, 1u)] = key;
-}
-
 // two-level exclusive scan: blocks of 1024
 constexpr int SCAN_BLOCK = 1024;
 static __global__ __launch_bounds__(SCAN_BLOCK) void scan_block_kernel(const uint32_t* __restrict__ in, uint32_t n,
@@ -236,6 +225,37 @@ static __global__ __launch_bounds__(SCAN_BLOCK) void scan_block_kernel(const uin
     }
     if (i < n) out[i] = sh[threadIdx.x] - v;  // exclusive
     if (threadIdx.x == SCAN_BLOCK - 1) block_sums[blockIdx.x] = sh[threadIdx.x];
+}
+// the run counts are computed on the fly from the bucket offsets and scanned in the same launch (first level of the
+// run-offset scan); buckets with many runs go to big_list, filled from the front with wave-tier buckets and from the
+// back with workgroup-tier buckets (big_count[0] / big_count[1] are the two lengths, zeroed by digits_kernel)
+static __global__ __launch_bounds__(SCAN_BLOCK) void runs_scan_block_kernel(const uint32_t* __restrict__ bucket_start, uint32_t n_keys,
+                                                                            uint32_t seg_len, uint32_t* __restrict__ out,
+                                                                            uint32_t* __restrict__ block_sums,
+                                                                            uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count) {
+    __shared__ uint32_t sh[SCAN_BLOCK / 64];
+    const uint32_t key = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    uint32_t r = 0;
+    if (key < n_keys) {
+        const uint32_t s0 = bucket_start[key], s1 = bucket_start[key + 1];
+        r = s1 > s0 ? 1 + (s1 - 1) / seg_len - s0 / seg_len : 0;
+        if (r > COMBINE_WAVE_MAX) big_list[n_keys - 1 - atomicAdd(big_count + 1, 1u)] = key;
+        else if (r > COMBINE_SMALL_MAX) big_list[atomicAdd(big_count, 1u)] = key;
+    }
+    // wave-level inclusive scan, then the 16 wave totals
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = r;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += o;
+    }
+    if (lane == 63) sh[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w2 = 0; w2 < wave; ++w2) before += sh[w2];
+    if (key < n_keys) out[key] = before + incl - r;  // exclusive
+    if (threadIdx.x == SCAN_BLOCK - 1) block_sums[blockIdx.x] = before + incl;
 }
 // single block: exclusive scan of the block sums in place (n_blocks <= 1024 * 64)
 static __global__ __launch_bounds__(SCAN_BLOCK) void scan_sums_kernel(uint32_t* sums, uint32_t n_blocks, uint32_t* grand_total) {
@@ -267,7 +287,7 @@ static __global__ void scan_add_kernel(uint32_t* out, uint32_t n, const uint32_t
 
 static __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const uint16_t* __restrict__ dig, uint32_t n, uint32_t dstride, int c,
                                                                int w_first, int w_count, int nchunk, uint32_t chunk_len,
-                                                               int shared_buckets, uint32_t table_stride,
+                                                               int shared_buckets, uint32_t table_stride, int table_w0,
                                                                const uint32_t* __restrict__ hist,
                                                                const uint32_t* __restrict__ bucket_start,
                                                                uint32_t* __restrict__ sorted) {
@@ -295,7 +315,7 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const uint
     if (hi > n) hi = n;
     const uint16_t* d = dig + (size_t)w * dstride;
     // with shared buckets the point reference addresses the precomputed table row (w, i)
-    const uint32_t ref_base = shared_buckets ? (uint32_t)w * table_stride : 0;
+    const uint32_t ref_base = shared_buckets ? (uint32_t)(w - table_w0) * table_stride : 0;  // table rows start at the plan's first window
     for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
         int v = (int)d[i] - (int)B;
         if (v != 0) {
@@ -364,22 +384,41 @@ static __global__ __launch_bounds__(SORT_THREADS) void hist_hi_kernel(const uint
     for (uint32_t b = threadIdx.x; b < NB; b += SORT_THREADS) out[b] = lds[b];
 }
 
-// counts[(wl, chunk, bin)] -> start offsets in (window, bin, chunk) order, in place; bin_start[(wl, bin)] (+ the grand
-// total as last entry, also stored at *total_out = bucket_start[n_keys]).  One workgroup; pairs = w_count * NB <= 4096.
-static __global__ __launch_bounds__(1024) void bins_scan_kernel(uint32_t* __restrict__ hist, int w_count /* bucket sets */, int nchunk /* sub-histograms per set */, uint32_t NB,
+// counts[(set, sub, bin)] -> start offsets in (set, bin, sub) order, in place; bin_start[(set, bin)] (+ the grand
+// total as last entry, also stored at *total_out = bucket_start[n_keys]).  One workgroup; pairs = sets * NB <= 4096.
+// The sub-histograms of a (set, bin) pair are cut into `tpp` contiguous slices, one thread each, with the bin index
+// running fastest over the lanes (coalesced rows of the histogram): a window-range run of a sharded MSM has few pairs and
+// many sub-histograms per pair, and a thread per pair would walk them one dependent load at a time (44 us for two windows).
+static __global__ __launch_bounds__(1024) void bins_scan_kernel(uint32_t* __restrict__ hist, int sets, int subs /* sub-histograms per set */, uint32_t NB,
                                                                 uint32_t* __restrict__ bin_start, uint32_t* __restrict__ total_out) {
     __shared__ uint32_t tot[4096];
-    const uint32_t pairs = (uint32_t)w_count * NB;
-    for (uint32_t p = threadIdx.x; p < pairs; p += blockDim.x) {
-        const uint32_t wl = p / NB, bin = p % NB;
+    __shared__ uint32_t ssum[4096];
+    __shared__ uint32_t sums[1024];
+    const uint32_t pairs = (uint32_t)sets * NB;
+    uint32_t tpp = pairs >= 4096 ? 1u : 4096u / pairs;   // slices per pair (power of two: NB is one, sets need not be)
+    while (tpp & (tpp - 1)) tpp &= tpp - 1;
+    if (tpp > (uint32_t)subs) tpp = 1u << (31 - __clz(subs));
+    const uint32_t slice_len = ((uint32_t)subs + tpp - 1) / tpp;
+    const uint32_t items = pairs * tpp;                    // <= 4096
+    // item = (set, slice, bin), bin fastest
+    for (uint32_t it = threadIdx.x; it < items; it += blockDim.x) {
+        const uint32_t bin = it % NB, sl = (it / NB) % tpp, set = it / (NB * tpp);
+        const uint32_t ch0 = sl * slice_len, ch1 = min((uint32_t)subs, ch0 + slice_len);
         uint32_t t = 0;
-        for (int ch = 0; ch < nchunk; ++ch) t += hist[((size_t)wl * nchunk + ch) * NB + bin];
+#pragma unroll 8
+        for (uint32_t ch = ch0; ch < ch1; ++ch) t += hist[((size_t)set * subs + ch) * NB + bin];
+        ssum[it] = t;
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < pairs; p += blockDim.x) {
+        const uint32_t set = p / NB, bin = p % NB;
+        uint32_t t = 0;
+        for (uint32_t sl = 0; sl < tpp; ++sl) t += ssum[(set * tpp + sl) * NB + bin];
         tot[p] = t;
     }
     __syncthreads();
     {
         // exclusive scan of tot[0 .. pairs): four consecutive entries per thread, then a Hillis-Steele scan of the 1024 sums
-        __shared__ uint32_t sums[1024];
         uint32_t v[4], sum = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -408,12 +447,14 @@ static __global__ __launch_bounds__(1024) void bins_scan_kernel(uint32_t* __rest
         }
     }
     __syncthreads();
-    for (uint32_t p = threadIdx.x; p < pairs; p += blockDim.x) {
-        const uint32_t wl = p / NB, bin = p % NB;
-        uint32_t run = tot[p];
-        bin_start[p] = run;
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const size_t idx = ((size_t)wl * nchunk + ch) * NB + bin;
+    for (uint32_t p = threadIdx.x; p < pairs; p += blockDim.x) bin_start[p] = tot[p];
+    for (uint32_t it = threadIdx.x; it < items; it += blockDim.x) {
+        const uint32_t bin = it % NB, sl = (it / NB) % tpp, set = it / (NB * tpp);
+        const uint32_t ch0 = sl * slice_len, ch1 = min((uint32_t)subs, ch0 + slice_len);
+        uint32_t run = tot[set * NB + bin];
+        for (uint32_t k = 0; k < sl; ++k) run += ssum[(set * tpp + k) * NB + bin];
+        for (uint32_t ch = ch0; ch < ch1; ++ch) {
+            const size_t idx = ((size_t)set * subs + ch) * NB + bin;
             uint32_t t = hist[idx];
             hist[idx] = run;
             run += t;
@@ -430,7 +471,7 @@ constexpr uint32_t SCATTER_TILE = SORT_THREADS * 8;
 
 static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_staged_kernel(const uint16_t* __restrict__ dig, uint32_t n, uint32_t dstride, int c,
                                                                                 int w_first, int nchunk, uint32_t chunk_len, int fine_log,
-                                                                                int shared_buckets, uint32_t table_stride,
+                                                                                int shared_buckets, uint32_t table_stride, int table_w0,
                                                                                 const uint32_t* __restrict__ offsets,
                                                                                 uint32_t* __restrict__ tmp) {
     extern __shared__ uint32_t lds[];
@@ -454,7 +495,7 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_staged_kernel(
     uint32_t lo = chunk * chunk_len, hi = lo + chunk_len;
     if (hi > n) hi = n;
     const uint16_t* d = dig + (size_t)(w_first + wl) * dstride;
-    const uint32_t ref_base = shared_buckets ? (uint32_t)(w_first + wl) * table_stride : 0;
+    const uint32_t ref_base = shared_buckets ? (uint32_t)(w_first + wl - table_w0) * table_stride : 0;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (uint32_t base = lo; base < hi; base += SCATTER_TILE) {
         const uint32_t i = base + threadIdx.x * 8;
@@ -733,87 +774,75 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const uint32_t* __restr
 }
 
 // ---- 6. combine ---------------------------------------------------------------------------------
+// bucket = sum of its runs, three tiers in ONE launch (every dependent launch costs ~5 us of latency, and the two upper
+// tiers are empty unless the scalars are skewed).  A point is held by a lane pair (pair.cuh) in all tiers.
+//   blocks [0, small_blocks)                 one pair per bucket with 2 .. COMBINE_SMALL_MAX runs
+//   blocks [small_blocks, + COMBINE_WAVE_BLOCKS)  one wave (32 pairs) per listed bucket, <= COMBINE_WAVE_MAX runs
+//   the rest                                 one workgroup (128 pairs) per listed bucket
+constexpr int COMBINE_THREADS = 256;
+constexpr uint32_t COMBINE_WAVE_BLOCKS = 128, COMBINE_BIG_BLOCKS = 64;
 
 template <class G>
-__global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict__ partials,
-                                                      const uint32_t* __restrict__ run_start, uint32_t n_keys,
-                                                      uint32_t* __restrict__ buckets) {
-    typedef typename G::F F;
-    constexpr int XW = 4 * F::LIMBS;
-    uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
-    if (key >= n_keys) return;
-    uint32_t s0 = run_start[key], s1 = run_start[key + 1];
-    if (s1 - s0 > COMBINE_SMALL_MAX) return;  // combine_big_kernel owns this bucket
-    if (s1 - s0 == 1) return;                 // a single run: accumulate_kernel wrote the bucket itself
-    XYZZ<F> acc = xyzz_inf<F>();
-    if (s1 > s0) acc = load_xyzz<F>(partials + (size_t)s0 * XW);
-    for (uint32_t s = s0 + 1; s < s1; ++s) acc = xyzz_add<F>(acc, load_xyzz<F>(partials + (size_t)s * XW));
-    store_xyzz<F>(buckets + (size_t)key * XW, acc);
-}
-
-// wave tier: one wave per listed bucket, lanes stride over its runs, 6-level shuffle tree
-template <class G>
-__global__ __launch_bounds__(256) void combine_wave_kernel(const uint32_t* __restrict__ partials,
-                                                           const uint32_t* __restrict__ run_start,
-                                                           const uint32_t* __restrict__ big_list,
-                                                           const uint32_t* __restrict__ big_count,
-                                                           uint32_t* __restrict__ buckets) {
-    typedef typename G::F F;
-    constexpr int XW = 4 * F::LIMBS;
-    const uint32_t count = big_count[0];
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t b = wave; b < count; b += n_waves) {
-        const uint32_t key = big_list[b];
-        const uint32_t s0 = run_start[key], s1 = run_start[key + 1];
-        XYZZ<F> v = xyzz_inf<F>();
-        for (uint32_t s = s0 + lane; s < s1; s += 64) v = xyzz_add<F>(v, load_xyzz<F>(partials + (size_t)s * XW));
-        for (int m = 32; m >= 1; m >>= 1) {
-            XYZZ<F> other = shfl_xor_xyzz<F>(v, m);
-            v = xyzz_add<F>(v, other);
-        }
-        if (lane == 0) store_xyzz<F>(buckets + (size_t)key * XW, v);
-    }
-}
-
-// workgroup tier: lanes stride over the runs, then a log-depth tree through LDS
-constexpr int BIG_THREADS = 256;
-template <class G>
-__global__ __launch_bounds__(BIG_THREADS) void combine_big_kernel(const uint32_t* __restrict__ partials,
-                                                                  const uint32_t* __restrict__ run_start,
-                                                                  const uint32_t* __restrict__ big_list, uint32_t n_keys,
+__global__ __launch_bounds__(COMBINE_THREADS) void combine_kernel(const uint32_t* __restrict__ partials,
+                                                                  const uint32_t* __restrict__ run_start, uint32_t n_keys,
+                                                                  uint32_t small_blocks, const uint32_t* __restrict__ big_list,
                                                                   const uint32_t* __restrict__ big_count,
                                                                   uint32_t* __restrict__ buckets) {
     typedef typename G::F F;
     constexpr int XW = 4 * F::LIMBS;
-    constexpr int RW = XyzzRegs<F>::COUNT;
-    __shared__ uint32_t sh[BIG_THREADS * RW];
-    const uint32_t count = big_count[1];
-    const uint32_t j = threadIdx.x;
-    for (uint32_t b = blockIdx.x; b < count; b += gridDim.x) {
-        const uint32_t key = big_list[n_keys - 1 - b];
+    constexpr int HW = HalfRegs<F>::COUNT;
+    __shared__ uint32_t sh[COMBINE_THREADS * HW];
+    const bool odd = (threadIdx.x & 1) != 0;
+    if (blockIdx.x < small_blocks) {
+        const uint32_t key = (blockIdx.x * COMBINE_THREADS + threadIdx.x) >> 1;
+        if (key >= n_keys) return;
         const uint32_t s0 = run_start[key], s1 = run_start[key + 1];
-        XYZZ<F> v = xyzz_inf<F>();
-        for (uint32_t s = s0 + j; s < s1; s += BIG_THREADS) v = xyzz_add<F>(v, load_xyzz<F>(partials + (size_t)s * XW));
-        for (uint32_t off = BIG_THREADS / 2; off >= 1; off >>= 1) {
-            lds_put_xyzz<F>(sh + (size_t)j * RW, v);
-            __syncthreads();
-            if (j < off) {
-                XYZZ<F> o = lds_get_xyzz<F>(sh + (size_t)(j + off) * RW);
-                v = xyzz_add<F>(v, o);
-            }
-            __syncthreads();
+        // a single run: accumulate_kernel wrote the bucket itself; no run: it is never read... but the reduction reads
+        // every bucket, so an empty one is set to infinity here
+        if (s1 - s0 == 1 || s1 - s0 > COMBINE_SMALL_MAX) return;
+        HalfPt<F> acc = half_inf<F>();
+        if (s1 > s0) acc = half_load<F>(partials + (size_t)s0 * XW, odd);
+        for (uint32_t r = s0 + 1; r < s1; ++r) acc = pair_add<F>(acc, half_load<F>(partials + (size_t)r * XW, odd), odd);
+        half_store<F>(buckets + (size_t)key * XW, odd, acc);
+    } else if (blockIdx.x < small_blocks + COMBINE_WAVE_BLOCKS) {
+        const uint32_t count = big_count[0];
+        const uint32_t lane = threadIdx.x & 63, pair = lane >> 1;
+        const uint32_t wave = ((blockIdx.x - small_blocks) * COMBINE_THREADS + threadIdx.x) >> 6;
+        const uint32_t n_waves = (COMBINE_WAVE_BLOCKS * COMBINE_THREADS) >> 6;
+        for (uint32_t b = wave; b < count; b += n_waves) {
+            const uint32_t key = big_list[b];
+            const uint32_t s0 = run_start[key], s1 = run_start[key + 1];
+            HalfPt<F> v = half_inf<F>();
+            for (uint32_t r = s0 + pair; r < s1; r += 32) v = pair_add<F>(v, half_load<F>(partials + (size_t)r * XW, odd), odd);
+            for (int m = 32; m >= 2; m >>= 1) v = pair_add<F>(v, half_shfl_xor<F>(v, m), odd);
+            if (lane < 2) half_store<F>(buckets + (size_t)key * XW, odd, v);
         }
-        if (j == 0) store_xyzz<F>(buckets + (size_t)key * XW, v);
+    } else {
+        const uint32_t count = big_count[1];
+        const uint32_t j = threadIdx.x, pair = j >> 1;
+        for (uint32_t b = blockIdx.x - small_blocks - COMBINE_WAVE_BLOCKS; b < count; b += COMBINE_BIG_BLOCKS) {
+            const uint32_t key = big_list[n_keys - 1 - b];
+            const uint32_t s0 = run_start[key], s1 = run_start[key + 1];
+            HalfPt<F> v = half_inf<F>();
+            for (uint32_t r = s0 + pair; r < s1; r += COMBINE_THREADS / 2) v = pair_add<F>(v, half_load<F>(partials + (size_t)r * XW, odd), odd);
+            for (uint32_t off = COMBINE_THREADS / 4; off >= 1; off >>= 1) {  // tree over the 128 pairs
+                half_lds_put<F>(sh, COMBINE_THREADS, j, v);
+                __syncthreads();
+                if (pair < off) v = pair_add<F>(v, half_lds_get<F>(sh, COMBINE_THREADS, j + 2 * off), odd);
+                __syncthreads();
+            }
+            if (j < 2) half_store<F>(buckets + (size_t)key * XW, odd, v);
+        }
     }
 }
 
 // ---- 7. bucket reduction ----------------------------------------------------------------------------
+// Both kernels hold a point as a lane pair (pair.cuh): an addition is seven multiplications deep instead of
+// fourteen and a half, which is what these latency-bound stages are made of.
 
-// Two strided sums in one launch (rows and columns run side by side: the stage is latency-bound, few waves):
+// Two strided sums in one launch (rows and columns run side by side):
 //   out[o] = sum_{j < count} in[(o / per_group) * group_stride + (o % per_group) * outer + j * inner]
-// one wave per output element; lanes stride over j, then a 6-level shuffle tree.
+// lpo lanes = lpo / 2 pairs per output element; the pairs stride over j, then a shuffle tree over the pairs.
 struct SumJob {
     uint32_t n_out, per_group, group_stride, outer, inner, count;
     uint32_t out_offset;  // in points, into the shared output array
@@ -822,14 +851,13 @@ struct SumJob {
 template <class G>
 __global__ __launch_bounds__(256) void strided_sum_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                           SumJob j0, SumJob j1, uint32_t lpo) {
-    // lpo lanes per output (16 or 64): with many outputs (one bucket set per window) 16 lanes each do
-    // count/16 sequential additions and a 4-level tree, which wastes far fewer lanes than a 6-level tree;
-    // with few outputs (shared bucket set) the stage is latency-bound and 64 lanes give the shortest chain.
     typedef typename G::F F;
     constexpr int XW = 4 * F::LIMBS;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t o = gid / lpo;
     const uint32_t sub = gid % lpo;
+    const bool odd = (sub & 1) != 0;
+    const uint32_t pair = sub >> 1, n_pairs = lpo >> 1;
     SumJob job = j0;
     if (o >= j0.n_out) {
         o -= j0.n_out;
@@ -837,61 +865,70 @@ __global__ __launch_bounds__(256) void strided_sum_kernel(const uint32_t* __rest
     }
     const bool live = o < job.n_out;  // dead groups still take part in the shuffles
     size_t base = live ? (size_t)(o / job.per_group) * job.group_stride + (size_t)(o % job.per_group) * job.outer : 0;
-    XYZZ<F> acc = xyzz_inf<F>();
+    HalfPt<F> acc = half_inf<F>();
     if (live) {
-        for (uint32_t j = sub; j < job.count; j += lpo) {
-            XYZZ<F> p = load_xyzz<F>(in + (base + (size_t)j * job.inner) * XW);
-            acc = xyzz_add<F>(acc, p);
+        for (uint32_t j = pair; j < job.count; j += n_pairs) {
+            HalfPt<F> h = half_load<F>(in + (base + (size_t)j * job.inner) * XW, odd);
+            acc = pair_add<F>(acc, h, odd);
         }
     }
-    for (uint32_t m = lpo >> 1; m >= 1; m >>= 1) {
-        XYZZ<F> other = shfl_xor_xyzz<F>(acc, (int)m);
-        acc = xyzz_add<F>(acc, other);
+    for (uint32_t m = lpo >> 1; m >= 2; m >>= 1) {
+        HalfPt<F> other = half_shfl_xor<F>(acc, (int)m);
+        acc = pair_add<F>(acc, other, odd);
     }
-    if (live && sub == 0) store_xyzz<F>(out + ((size_t)job.out_offset + o) * XW, acc);
+    if (live && sub < 2) half_store<F>(out + ((size_t)job.out_offset + o) * XW, odd, acc);
 }
 
-// one workgroup per array of m <= 256 points: S = sum_j j * X_j and T = sum_j X_j
-// via an inclusive suffix scan (log m steps) followed by a tree sum of the suffixes 1..m-1.
-// Blocks [0, n0) take arrays of m0 points from in0, blocks [n0, ..) arrays of m1 points from in1.
-constexpr int HS_THREADS = 256;
+// S = sum_j j * X_j and T = sum_j X_j over BLOCKS of at most WS_BLOCK points of the input arrays, one workgroup per
+// block, two lanes per point (so a workgroup is four waves: one per SIMD of its CU), via an inclusive suffix scan
+// (log m steps) followed by a tree sum of the suffixes 1..m-1.  n0 arrays of m0 points from in0, then arrays of m1
+// points from in1; block k of an array covers its points [k WS_BLOCK, ..) with LOCAL weights 0, 1, ..: the host tail adds
+// k WS_BLOCK T_k along its Horner chain, where those doublings cost nothing extra.  out: (S, T) per block, arrays of
+// in0 first.  Dynamic LDS: HalfRegs<F>::COUNT words per lane, word-major.
+constexpr int WS_BLOCK = 128;
+constexpr int WS_BLOCK_LOG = 7;
+constexpr int HS_THREADS = 2 * WS_BLOCK;
 template <class G>
 __global__ __launch_bounds__(HS_THREADS) void weighted_sum_kernel(const uint32_t* __restrict__ in0, uint32_t m0, uint32_t n0,
                                                                   const uint32_t* __restrict__ in1, uint32_t m1,
                                                                   uint32_t* __restrict__ out) {
     typedef typename G::F F;
     constexpr int XW = 4 * F::LIMBS;
-    constexpr int RW = XyzzRegs<F>::COUNT;
-    __shared__ uint32_t sh[HS_THREADS * RW];
-    const uint32_t j = threadIdx.x;
-    const bool first = blockIdx.x < n0;
-    const uint32_t m = first ? m0 : m1;
-    const uint32_t* arr = first ? in0 + (size_t)blockIdx.x * m0 * XW : in1 + (size_t)(blockIdx.x - n0) * m1 * XW;
-    XYZZ<F> v = j < m ? load_xyzz<F>(arr + (size_t)j * XW) : xyzz_inf<F>();
+    extern __shared__ uint32_t sh[];
+    const uint32_t tid = threadIdx.x, pj = tid >> 1;
+    const bool odd = (tid & 1) != 0;
+    const uint32_t bpa0 = (m0 + WS_BLOCK - 1) / WS_BLOCK, bpa1 = (m1 + WS_BLOCK - 1) / WS_BLOCK;
+    const bool first = blockIdx.x < n0 * bpa0;
+    const uint32_t rel = first ? blockIdx.x : blockIdx.x - n0 * bpa0;
+    const uint32_t bpa = first ? bpa0 : bpa1, ma = first ? m0 : m1;
+    const uint32_t arr_i = rel / bpa, blk = rel % bpa;
+    const uint32_t m = min((uint32_t)WS_BLOCK, ma - blk * WS_BLOCK);
+    const uint32_t* arr = (first ? in0 : in1) + ((size_t)arr_i * ma + (size_t)blk * WS_BLOCK) * XW;
+    HalfPt<F> v = pj < m ? half_load<F>(arr + (size_t)pj * XW, odd) : half_inf<F>();
     for (uint32_t off = 1; off < m; off <<= 1) {
-        lds_put_xyzz<F>(sh + (size_t)j * RW, v);
+        half_lds_put<F>(sh, HS_THREADS, tid, v);
         __syncthreads();
-        if (j + off < m) {
-            XYZZ<F> o = lds_get_xyzz<F>(sh + (size_t)(j + off) * RW);
-            v = xyzz_add<F>(v, o);
+        if (pj + off < m) {
+            HalfPt<F> o = half_lds_get<F>(sh, HS_THREADS, tid + 2 * off);
+            v = pair_add<F>(v, o, odd);
         }
         __syncthreads();
     }
     // v = suffix sum s_j
-    if (j == 0) store_xyzz<F>(out + ((size_t)blockIdx.x * 2 + 1) * XW, v);  // T = s_0
-    if (j == 0 || j >= m) v = xyzz_inf<F>();
+    if (pj == 0) half_store<F>(out + ((size_t)blockIdx.x * 2 + 1) * XW, odd, v);  // T = s_0
+    if (pj == 0 || pj >= m) v = half_inf<F>();
     uint32_t top = 1;
     while (top < m) top <<= 1;
     for (uint32_t off = top / 2; off >= 1; off >>= 1) {
-        lds_put_xyzz<F>(sh + (size_t)j * RW, v);
+        half_lds_put<F>(sh, HS_THREADS, tid, v);
         __syncthreads();
-        if (j < off) {
-            XYZZ<F> o = lds_get_xyzz<F>(sh + (size_t)(j + off) * RW);
-            v = xyzz_add<F>(v, o);
+        if (pj < off) {
+            HalfPt<F> o = half_lds_get<F>(sh, HS_THREADS, tid + 2 * off);
+            v = pair_add<F>(v, o, odd);
         }
         __syncthreads();
     }
-    if (j == 0) store_xyzz<F>(out + (size_t)blockIdx.x * 2 * XW, v);  // S
+    if (pj == 0) half_store<F>(out + (size_t)blockIdx.x * 2 * XW, odd, v);  // S
 }
 
 // ---- bases: canonical -> Montgomery; batch scalar multiplication -------------------------------------
@@ -910,66 +947,14 @@ __global__ void bases_to_mont_kernel(const uint32_t* __restrict__ in, uint64_t n
     store_affine<F>(out + i * AW, p);
 }
 
-// ZK_MSM_PRECOMPUTE: table[w][i] = 2^(c w) * P_i (affine, Montgomery) for w = 1 .. nwin-1; row 0 is the input.
-// With these rows every window adds into ONE shared bucket set: the bucket reduction and the host tail shrink
-// by the number of windows and the Horner pass disappears.  One lane per point, c doublings per row and one
-// inversion per row (a one-time cost per proving key: ~8k field products per point).
-template <class G>
-__global__ __launch_bounds__(256) void precompute_kernel(uint32_t* __restrict__ table, uint32_t n, int c, int nwin) {
-    typedef typename G::F F;
-    constexpr int AW = 2 * F::LIMBS;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Affine<F> p = load_affine<F>(table + (size_t)i * AW);
-    for (int w = 1; w < nwin; ++w) {
-        XYZZ<F> acc = xyzz_dbl_affine<F>(p);
-        for (int k = 1; k < c; ++k) acc = xyzz_dbl<F>(acc);
-        p = xyzz_to_affine<F>(acc);
-        store_affine<F>(table + ((size_t)w * n + i) * AW, p);
-    }
-}
-
-// out[i] = k_i * P_i (affine, canonical).  broadcast: one base for all.
-template <class G>
-__global__ __launch_bounds__(128) void batch_mul_kernel(const uint32_t* __restrict__ scalars,
-                                                        const uint32_t* __restrict__ bases, int broadcast, uint64_t n,
-                                                        uint32_t* __restrict__ out) {
-    typedef typename G::F F;
-    typedef typename G::Fr FrP;
-    constexpr int AW = 2 * F::LIMBS;
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t k[FrP::W];
-    load_words<FrP::W>(k, scalars + i * FrP::W);
-    for (int r = 0; r < 10; ++r) {
-        uint32_t t[FrP::W];
-        if (fp_sub_mod_raw<FrP>(t, k)) break;
-#pragma unroll
-        for (int l = 0; l < FrP::W; ++l) k[l] = t[l];
-    }
-    uint32_t w[AW];
-    load_words<AW>(w, bases + (broadcast ? 0 : i * AW));
-    Affine<F> p;
-    p.x = F::from_canonical(w);
-    p.y = F::from_canonical(w + F::LIMBS);
-    XYZZ<F> acc = xyzz_scalar_mul<F>(p, k, FrP::W);
-    Affine<F> a = xyzz_to_affine<F>(acc);
-    F::to_canonical(w, a.x);
-    F::to_canonical(w + F::LIMBS, a.y);
-    store_words<AW>(out + i * AW, w);
-}
-
 #if defined(ZK_GROUP) && (!defined(ZK_PART) || ZK_PART == 0)
 // the plan's translation unit does not instantiate the heavy kernels (see msm_group.hip)
 extern template __global__ void accumulate_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*);
-extern template __global__ void precompute_kernel<ZK_GROUP>(uint32_t*, uint32_t, int, int);
-extern template __global__ void batch_mul_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, int, uint64_t, uint32_t*);
 extern template __global__ void bases_to_mont_kernel<ZK_GROUP>(const uint32_t*, uint64_t, uint32_t*);
-extern template __global__ void combine_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, uint32_t, uint32_t*);
-extern template __global__ void combine_wave_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*);
-extern template __global__ void combine_big_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const uint32_t*, uint32_t*);
+extern template __global__ void combine_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*);
 extern template __global__ void strided_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t*, SumJob, SumJob, uint32_t);
 extern template __global__ void weighted_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t, uint32_t, const uint32_t*, uint32_t, uint32_t*);
+ZK_SETUP_EXTERN_TEMPLATES(ZK_GROUP)
 #endif
 
 #if !defined(ZK_PART) || ZK_PART == 0
@@ -985,100 +970,196 @@ static int pick_window_bits(uint64_t n) {
     return c;
 }
 
+// ZK_MSM_PRECOMPUTE: table row k = 2^(c (w_first + k)) * P_i (affine, Montgomery) for the w_count windows of the plan; on
+// entry row 0 holds the bases themselves.  With these rows every window adds into ONE shared bucket set: the bucket
+// reduction and the host tail shrink by the number of windows and the Horner pass disappears.  The chain of doublings
+// runs in XYZZ on a scratch vector; each row is normalised with the batched inversion (one Fermat inversion per 1024
+// points instead of one per point and row: 46 -> ~15 ms for a 2^20-point BN254 G1 key).
+template <class G>
+static int precompute_table(uint32_t* table, uint64_t n, int c, int w_first, int w_count) {
+    typedef typename G::F F;
+    constexpr int AW = 2 * F::LIMBS, XW = 4 * F::LIMBS;
+    if (w_first == 0 && w_count == 1) return ZK_OK;
+    uint32_t* temp = nullptr;
+    ZK_HIP(hipMalloc(&temp, n * XW * 4));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    const unsigned nblocks = (unsigned)((n + (uint64_t)NORM_THREADS * NORM_E - 1) / ((uint64_t)NORM_THREADS * NORM_E));
+    hipLaunchKernelGGL(dbl_rows_kernel<G>, dim3(blocks), dim3(256), 0, 0, temp, n, c * w_first, (const uint32_t*)table);
+    if (w_first > 0) hipLaunchKernelGGL(normalize_kernel<G>, dim3(nblocks), dim3(NORM_THREADS), 0, 0, temp, n, table, 0);
+    for (int k = 1; k < w_count; ++k) {
+        hipLaunchKernelGGL(dbl_rows_kernel<G>, dim3(blocks), dim3(256), 0, 0, temp, n, c, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL(normalize_kernel<G>, dim3(nblocks), dim3(NORM_THREADS), 0, 0, temp, n, table + (size_t)k * n * AW, 0);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(temp);
+    ZK_HIP(e);
+    return ZK_OK;
+}
+
+// fixed-base table of the last broadcast base of this group (Groth16.setup multiplies the same generator five times)
+template <class G>
+struct FixedTable {
+    std::vector<uint64_t> base;   // canonical affine limbs the table was built for
+    uint32_t* d_table = nullptr;
+    int nwin = 0;
+    std::mutex mu;
+    static FixedTable& get() {
+        static FixedTable t;
+        return t;
+    }
+    void release() {
+        std::lock_guard<std::mutex> lock(mu);
+        if (d_table) (void)hipFree(d_table);
+        d_table = nullptr;
+        base.clear();
+    }
+    // caller holds mu
+    int ensure(const uint64_t* base_limbs) {
+        typedef typename G::F F;
+        typedef typename G::Fr FrP;
+        constexpr int AW = 2 * F::LIMBS, XW = 4 * F::LIMBS;
+        const size_t words64 = AW / 2;
+        if (d_table && base.size() == words64 && memcmp(base.data(), base_limbs, words64 * 8) == 0) return ZK_OK;
+        if (d_table) (void)hipFree(d_table);
+        d_table = nullptr;
+        base.clear();
+        nwin = (FrP::BITS + 1 + FIXED_C - 1) / FIXED_C;
+        // window bases 2^(16 j) G on the host (16 points)
+        std::vector<uint32_t> wb((size_t)nwin * AW);
+        {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(base_limbs);
+            Affine<F> g = {F::from_canonical(w), F::from_canonical(w + F::LIMBS)};
+            XYZZ<F> acc = xyzz_from_affine<F>(g);
+            for (int j = 0; j < nwin; ++j) {
+                Affine<F> a = xyzz_to_affine<F>(acc);
+                F::store(wb.data() + (size_t)j * AW, a.x);
+                F::store(wb.data() + (size_t)j * AW + F::LIMBS, a.y);
+                if (j + 1 < nwin) for (int k = 0; k < FIXED_C; ++k) acc = xyzz_dbl<F>(acc);
+            }
+        }
+        const uint64_t rows = (uint64_t)nwin * FIXED_HALF;
+        uint32_t *d_wb = nullptr, *temp = nullptr;
+        ZK_HIP(hipMalloc(&d_table, rows * AW * 4));
+        hipError_t e = hipMalloc(&d_wb, wb.size() * 4);
+        if (e == hipSuccess) e = hipMalloc(&temp, rows * XW * 4);
+        if (e == hipSuccess) e = hipMemcpy(d_wb, wb.data(), wb.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(fixed_table_kernel<G>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, 0, d_wb, nwin, temp);
+            hipLaunchKernelGGL(normalize_kernel<G>, dim3((unsigned)((rows + (uint64_t)NORM_THREADS * NORM_E - 1) / ((uint64_t)NORM_THREADS * NORM_E))),
+                               dim3(NORM_THREADS), 0, 0, temp, rows, d_table, 0);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        if (d_wb) (void)hipFree(d_wb);
+        if (temp) (void)hipFree(temp);
+        if (e != hipSuccess) {
+            (void)hipFree(d_table);
+            d_table = nullptr;
+            return fail(ZK_ERR_HIP, std::string("fixed-base table: ") + hipGetErrorString(e));
+        }
+        base.assign(base_limbs, base_limbs + words64);
+        return ZK_OK;
+    }
+};
+
+// host-side facade of the tail: the device field facade plus the two conversions the tail needs
+template <class F>
+struct HostTail29 : F {
+    static XYZZ<HostTail29> xyzz_from_device(const uint32_t* w) {
+        return {F::load(w), F::load(w + F::LIMBS), F::load(w + 2 * F::LIMBS), F::load(w + 3 * F::LIMBS)};
+    }
+    static void affine_to_canonical(const Affine<HostTail29>& a, uint64_t* out) {
+        uint32_t w[2 * F::LIMBS];
+        F::to_canonical(w, a.x);
+        F::to_canonical(w + F::LIMBS, a.y);
+        memcpy(out, w, sizeof(w));
+    }
+};
+
 template <class G>
 struct MsmPlan : MsmPlanBase {
     typedef typename G::F F;
     typedef typename G::Fr FrP;
     static constexpr int AW = 2 * F::LIMBS;
     static constexpr int XW = 4 * F::LIMBS;
-    static constexpr int MAX_LANES = 4;
     static constexpr uint64_t SEG_TARGET_LANES = 256ull * 1024;  // 4 waves per SIMD on 256 CUs
 
-    // A run can be split over `n_lanes` groups of windows ("lanes"), each with its own stream and workspace
-    // (meant to let one group's latency-bound reduction run beside the next group's accumulation; see init()
-    // for why the default is one lane).
-    struct Lane {
-        uint32_t *hist = nullptr, *total = nullptr, *nseg = nullptr, *bstart = nullptr, *sstart = nullptr;
+    // device workspace of one run (stages 2..7)
+    struct Work {
+        uint32_t *hist = nullptr, *total = nullptr, *bstart = nullptr, *sstart = nullptr;
         uint32_t *bsums = nullptr, *grand = nullptr, *big_list = nullptr, *big_count = nullptr;
         uint32_t *sorted = nullptr, *partials = nullptr, *buckets = nullptr, *rows = nullptr, *fin = nullptr;
-        uint32_t *tmp_ref = nullptr, *bin_start = nullptr;  // two-level sort (general mode)
-        hipStream_t stream = nullptr;
+        uint32_t *tmp_ref = nullptr, *bin_start = nullptr;  // two-level sort
         hipEvent_t ev_begin = nullptr, ev_acc0 = nullptr, ev_acc1 = nullptr, ev_done = nullptr;
         int w_first = 0, w_count = 0;  // windows of the run in flight
         uint32_t groups = 0;           // bucket sets of the run in flight
-        size_t h_offset = 0;           // words into h_final
     };
 
     uint64_t n = 0;
     bool pre = false;  // ZK_MSM_PRECOMPUTE: shared bucket set over a table of 2^(c w) P_i
+    int pw_first = 0, pw_count = 0;  // windows this plan can run (a sharded rank's share; all of them by default)
     uint32_t B = 0, R = 0, C = 0;
-    int nchunk = 0;
+    uint32_t bpr = 0, bpc = 0;       // weighted-sum blocks per row array / per column array
     int range_log = 0;  // general mode: log2(buckets per sort workgroup)
-    uint32_t seg_len = 0;
-    int n_lanes = 1, lane_windows = 0;
-    Lane lanes[MAX_LANES];
+    Work ws;
     // shared device buffers
     uint32_t* d_bases = nullptr;
     uint32_t* d_scalars = nullptr;
     uint16_t* d_dig = nullptr;
-    uint32_t* h_final = nullptr;  // pinned: per bucket set (S_R, T, S_C, -)
+    uint32_t* h_final = nullptr;  // pinned: (S, T) per weighted-sum block
     hipEvent_t ev_start = nullptr, ev_digits = nullptr, ev_end = nullptr;
 
     ~MsmPlan() override {
-        for (Lane& l : lanes) {
-            void* bufs[] = {l.hist, l.total, l.nseg, l.bstart, l.sstart, l.bsums, l.grand, l.big_list, l.big_count,
-                            l.sorted, l.partials, l.buckets, l.rows, l.fin, l.tmp_ref, l.bin_start};
-            for (void* p : bufs) if (p) (void)hipFree(p);
-            if (l.stream) (void)hipStreamDestroy(l.stream);
-            for (hipEvent_t e : {l.ev_begin, l.ev_acc0, l.ev_acc1, l.ev_done}) if (e) (void)hipEventDestroy(e);
-        }
-        for (void* p : {(void*)d_bases, (void*)d_scalars, (void*)d_dig}) if (p) (void)hipFree(p);
+        void* bufs[] = {ws.hist, ws.total, ws.bstart, ws.sstart, ws.bsums, ws.grand, ws.big_list, ws.big_count,
+                        ws.sorted, ws.partials, ws.buckets, ws.rows, ws.fin, ws.tmp_ref, ws.bin_start,
+                        d_bases, d_scalars, d_dig};
+        for (void* q : bufs) if (q) (void)hipFree(q);
         if (h_final) (void)hipHostFree(h_final);
-        for (hipEvent_t e : {ev_start, ev_digits, ev_end}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ws.ev_begin, ws.ev_acc0, ws.ev_acc1, ws.ev_done, ev_start, ev_digits, ev_end}) if (e) (void)hipEventDestroy(e);
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
 
-    int init(uint64_t n_points, const void* bases, int bases_on_device, int flags, int window_bits) {
+    // Every allocation lands in a member that the destructor frees, and the factory deletes the plan when init() fails
+    // (msm_group.hip), so a failing hipMalloc half way through leaks nothing.
+    int init(uint64_t n_points, const void* bases, int bases_on_device, int flags, int window_bits, int win_first, int win_count) {
         pre = (flags & ZK_MSM_PRECOMPUTE) != 0;
         if (n_points == 0 || n_points > (1ull << 26)) return fail(ZK_ERR_ARG, "MSM size must be in [1, 2^26]");
         n = n_points;
         c = window_bits > 0 ? window_bits : pick_window_bits(n);
         if (c < 2 || c > 16) return fail(ZK_ERR_ARG, "window bits must be in [2, 16]");
         nwin = (FrP::BITS + 1 + c - 1) / c;
+        if (win_count <= 0) { win_first = 0; win_count = nwin; }
+        if (win_first < 0 || win_first + win_count > nwin) return fail(ZK_ERR_ARG, "window range out of bounds");
+        pw_first = win_first;
+        pw_count = win_count;
         B = 1u << (c - 1);
         int rl = (c - 1 + 1) / 2;
         if (rl > 8) rl = 8;
         R = 1u << rl;
         C = B / R;
         if (C > 256) return fail(ZK_ERR_ARG, "window too wide for the reduction stage");
-        // chunked sort: windows x chunks workgroups of 1024 threads, ONE per CU (the LDS histogram takes 128 KiB at
-        // c = 16), so their number is kept at or just below the 256 CUs: 272 workgroups would run as 256 + 16,
-        // i.e. take twice as long.  nchunk is the value for a full-window run; window-range runs recompute it.
-        nchunk = chunks_for(nwin, n);
+        bpr = (R + WS_BLOCK - 1) / WS_BLOCK;
+        bpc = (C + WS_BLOCK - 1) / WS_BLOCK;
         // bucket ranges (general mode, small inputs): about 256 sort workgroups in total, at least 64 buckets each
         {
             uint32_t wgs = 256u;
             if (const char* e = getenv("ZKMI_SORT_WGS")) wgs = (uint32_t)atoi(e);  // tuning knob
-            uint32_t want = std::max<uint32_t>(1u, wgs / (uint32_t)std::max(1, nwin));
+            uint32_t want = std::max<uint32_t>(1u, wgs / (uint32_t)std::max(1, pw_count));
             uint32_t per = std::max<uint32_t>(64u, B / want);
             if (per > B) per = B;
             range_log = log2_u64(per);
             if ((1u << range_log) > B) range_log = c - 1;
         }
-        seg_len = pick_seg_len((uint64_t)nwin * n);
-        uint64_t entries = (uint64_t)nwin * n;
+        const uint64_t entries = (uint64_t)pw_count * n;
         if (entries > 0x7FFFFFFFull) return fail(ZK_ERR_ARG, "MSM too large");
-        // measured at 2^20 (BN254 G1): 1 / 2 / 4 lanes -> 2.47 / 2.59 / 3.36 ms.  A full-occupancy accumulation kernel
-        // leaves no wave slots for another stream's reduction kernels, so the hoped-for overlap does not happen;
-        // the default is a single lane and the knob stays for experiments.
-        n_lanes = 1;
-        if (const char* e = getenv("ZKMI_LANES")) n_lanes = atoi(e);
-        if (n_lanes < 1) n_lanes = 1;
-        if (n_lanes > MAX_LANES) n_lanes = MAX_LANES;
-        if (n_lanes > nwin) n_lanes = nwin;
-        lane_windows = (nwin + n_lanes - 1) / n_lanes;
 
-        ZK_HIP(hipMalloc(&d_bases, (pre ? (uint64_t)nwin : 1ull) * n * AW * 4));
+        {
+            int lo = 0, hi = 0;
+            ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            ZK_HIP(hipStreamCreateWithPriority(&own_stream, hipStreamDefault, (flags & ZK_MSM_HIGH_PRIORITY) ? hi : lo));
+        }
+        ZK_HIP(hipMalloc(&d_bases, (pre ? (uint64_t)pw_count : 1ull) * n * AW * 4));
         if (bases_on_device) {
             hipLaunchKernelGGL(bases_to_mont_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0,
                                (const uint32_t*)bases, n, d_bases);
@@ -1095,42 +1176,38 @@ struct MsmPlan : MsmPlanBase {
         }
         ZK_HIP(hipGetLastError());
         if (pre) {
-            hipLaunchKernelGGL(precompute_kernel<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_bases, (uint32_t)n, c, nwin);
-            ZK_HIP(hipGetLastError());
+            // rows 2^(c w) P_i for the windows of this plan only (a sharded rank never builds the other ranks' rows)
+            int rc = precompute_table<G>(d_bases, n, c, pw_first, pw_count);
+            if (rc) return rc;
         }
         ZK_HIP(hipMalloc(&d_scalars, n * FrP::W * 4));
-        ZK_HIP(hipMalloc(&d_dig, (size_t)nwin * (n + 8) * 2));
-        ZK_HIP(hipHostMalloc(&h_final, (size_t)nwin * 4 * XW * 4));
+        ZK_HIP(hipMalloc(&d_dig, (size_t)pw_count * (n + 8) * 2));
+        const uint64_t max_sets = pre ? 1ull : (uint64_t)pw_count;
+        ZK_HIP(hipHostMalloc(&h_final, (size_t)max_sets * (bpr + bpc) * 2 * XW * 4));
         for (hipEvent_t* e : {&ev_start, &ev_digits, &ev_end}) ZK_HIP(hipEventCreate(e));
-        ZK_HIP(hipStreamCreate(&own_stream));
-        // per-lane workspaces: lane 0 can hold every window (single-lane runs), the others lane_windows windows
-        for (int i = 0; i < n_lanes; ++i) {
-            Lane& l = lanes[i];
-            const uint64_t lw = i == 0 ? (uint64_t)nwin : (uint64_t)lane_windows;
-            const uint64_t keys = (pre ? 1ull : lw) * B;
-            const uint64_t lane_entries = lw * n;
+        {
+            const uint64_t keys = max_sets * B;
             // a window-range run picks its own (shorter) segments: at most SEG_TARGET_LANES of them, or entries / 8
-            const uint64_t max_segs = std::max<uint64_t>(lane_entries / seg_len, std::min<uint64_t>(lane_entries / 8, SEG_TARGET_LANES)) + keys + 8;
-            ZK_HIP(hipMalloc(&l.hist, (size_t)std::max<uint64_t>(256, lw) * B * 4));  // windows x chunks <= max(256, windows)
-            ZK_HIP(hipMalloc(&l.total, keys * 4));
-            ZK_HIP(hipMalloc(&l.nseg, keys * 4));
-            ZK_HIP(hipMalloc(&l.bstart, (keys + 1) * 4));
-            ZK_HIP(hipMalloc(&l.sstart, (keys + 1) * 4));
-            ZK_HIP(hipMalloc(&l.bsums, ((keys + SCAN_BLOCK - 1) / SCAN_BLOCK + 1) * 4));
-            ZK_HIP(hipMalloc(&l.grand, 4));
-            ZK_HIP(hipMalloc(&l.big_list, keys * 4));
-            ZK_HIP(hipMalloc(&l.big_count, 8));
-            ZK_HIP(hipMalloc(&l.sorted, lane_entries * 4));
+            const uint32_t seg_full = pick_seg_len(entries);
+            const uint64_t max_segs = std::max<uint64_t>(entries / seg_full, std::min<uint64_t>(entries / 8, SEG_TARGET_LANES)) + keys + 8;
+            ZK_HIP(hipMalloc(&ws.hist, (size_t)std::max<uint64_t>(256, pw_count) * B * 4));  // windows x chunks <= max(256, windows)
+            ZK_HIP(hipMalloc(&ws.total, keys * 4));
+            ZK_HIP(hipMalloc(&ws.bstart, (keys + 1) * 4));
+            ZK_HIP(hipMalloc(&ws.sstart, (keys + 1) * 4));
+            ZK_HIP(hipMalloc(&ws.bsums, ((keys + SCAN_BLOCK - 1) / SCAN_BLOCK + 1) * 4));
+            ZK_HIP(hipMalloc(&ws.grand, 4));
+            ZK_HIP(hipMalloc(&ws.big_list, keys * 4));
+            ZK_HIP(hipMalloc(&ws.big_count, 8));
+            ZK_HIP(hipMalloc(&ws.sorted, entries * 4));
             if (two_level_ok()) {
-                ZK_HIP(hipMalloc(&l.tmp_ref, lane_entries * 4));
-                ZK_HIP(hipMalloc(&l.bin_start, ((pre ? 1 : lw) * (B >> fine_log_for(n)) + 1) * 4));
+                ZK_HIP(hipMalloc(&ws.tmp_ref, entries * 4));
+                ZK_HIP(hipMalloc(&ws.bin_start, (max_sets * (B >> fine_log_for(n)) + 1) * 4));
             }
-            ZK_HIP(hipMalloc(&l.partials, max_segs * XW * 4));
-            ZK_HIP(hipMalloc(&l.buckets, keys * XW * 4));
-            ZK_HIP(hipMalloc(&l.rows, lw * (R + C) * XW * 4));
-            ZK_HIP(hipMalloc(&l.fin, lw * 4 * XW * 4));
-            ZK_HIP(hipStreamCreate(&l.stream));
-            for (hipEvent_t* e : {&l.ev_begin, &l.ev_acc0, &l.ev_acc1, &l.ev_done}) ZK_HIP(hipEventCreate(e));
+            ZK_HIP(hipMalloc(&ws.partials, max_segs * XW * 4));
+            ZK_HIP(hipMalloc(&ws.buckets, keys * XW * 4));
+            ZK_HIP(hipMalloc(&ws.rows, max_sets * (R + C) * XW * 4));
+            ZK_HIP(hipMalloc(&ws.fin, max_sets * (bpr + bpc) * 2 * XW * 4));
+            for (hipEvent_t* e : {&ws.ev_begin, &ws.ev_acc0, &ws.ev_acc1, &ws.ev_done}) ZK_HIP(hipEventCreate(e));
         }
         // LDS above 64 KiB needs the opt-in
         int lds_bytes = (int)(B * 4);
@@ -1140,10 +1217,15 @@ struct MsmPlan : MsmPlanBase {
         ZK_HIP(hipFuncSetAttribute((const void*)scatter_range_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         ZK_HIP(hipFuncSetAttribute((const void*)scatter_hi_staged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         ZK_HIP(hipFuncSetAttribute((const void*)sort_lo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        ZK_HIP(hipFuncSetAttribute((const void*)weighted_sum_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(HalfRegs<F>::COUNT * HS_THREADS * 4)));
         ZK_HIP(hipDeviceSynchronize());
         return ZK_OK;
     }
 
+    // chunked sort: windows x chunks workgroups of 1024 threads, ONE per CU (the LDS histogram takes 128 KiB at
+    // c = 16), so their number is kept at or just below the 256 CUs: 272 workgroups would run as 256 + 16,
+    // i.e. take twice as long
     static int chunks_for(int windows, uint64_t count) {
         int k = 256 / std::max(1, windows);
         if (k < 1) k = 1;
@@ -1152,11 +1234,11 @@ struct MsmPlan : MsmPlanBase {
         return k;
     }
 
-    int exclusive_scan(Lane& l, const uint32_t* in, uint32_t cnt, uint32_t* out, hipStream_t st) {
+    int exclusive_scan(const uint32_t* in, uint32_t cnt, uint32_t* out, hipStream_t st) {
         uint32_t blocks = (cnt + SCAN_BLOCK - 1) / SCAN_BLOCK;
-        hipLaunchKernelGGL(scan_block_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, st, in, cnt, out, l.bsums);
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, l.bsums, blocks, l.grand);
-        hipLaunchKernelGGL(scan_add_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, st, out, cnt, l.bsums, l.grand);
+        hipLaunchKernelGGL(scan_block_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, st, in, cnt, out, ws.bsums);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, ws.bsums, blocks, ws.grand);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, st, out, cnt, ws.bsums, ws.grand);
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
@@ -1166,15 +1248,14 @@ struct MsmPlan : MsmPlanBase {
     int fine_log_for(uint64_t points) const {
         // fixed-base mode: ONE bucket set over references into the (window, point) table, so the references are wider
         // and the coarse bins are shared by all windows -- more, smaller bins keep level B parallel
-        const uint64_t refs = pre ? (uint64_t)nwin * points : points;
-        const uint64_t sets = pre ? 1 : (uint64_t)nwin;
+        const uint64_t refs = pre ? (uint64_t)pw_count * points : points;
+        const uint64_t sets = pre ? 1 : (uint64_t)pw_count;
         const int f_hi = pre ? 5 : FINE_LOG_MAX, f_lo = pre ? 4 : FINE_LOG_MAX - 1;
         for (int f = f_hi; f >= f_lo; --f)
             if (refs <= (1ull << (31 - f)) && c - 1 >= f + 2 && sets * (B >> f) <= 4096) return f;
         return 0;
     }
 
-    // the two-level sort needs its own bucket set per window (general mode)
     bool two_level_ok() const {
         static const bool off = getenv("ZKMI_NO_TWO_LEVEL") != nullptr;
         return !off && fine_log_for(n) > 0;
@@ -1184,11 +1265,12 @@ struct MsmPlan : MsmPlanBase {
     // run of a sharded MSM has far fewer entries than the plan's full set; with the plan-wide length its lanes would
     // be too few and each would walk 64 additions at lone-wave speed).
     uint32_t pick_seg_len(uint64_t entries) const {
-        uint64_t sl = (entries + SEG_TARGET_LANES - 1) / SEG_TARGET_LANES;
+        static const uint64_t target = getenv("ZKMI_SEG_LANES") ? (uint64_t)atoll(getenv("ZKMI_SEG_LANES")) : SEG_TARGET_LANES;
+        uint64_t sl = (entries + target - 1) / target;
         if (sl < 8) sl = 8;
         if (sl > 64) sl = 64;
         if (pre) {
-            // shared bucket set: keep a bucket within ~12 runs so that one lane can combine it
+            // shared bucket set: keep a bucket within ~12 runs so that one lane pair can combine it
             uint64_t per_bucket = entries / B;
             uint64_t want = (per_bucket + 11) / 12;
             if (want > sl) sl = want;
@@ -1197,18 +1279,19 @@ struct MsmPlan : MsmPlanBase {
         return (uint32_t)sl;
     }
 
-    // stages 2..7 + D2H for the windows [w_first, w_first + w_count) on stream st
-    int run_lane(Lane& l, uint32_t m, uint32_t dstride, hipStream_t st, hipEvent_t after_acc) {
+    // stages 2..7 + D2H for the windows [ws.w_first, ws.w_first + ws.w_count) on stream st
+    int run_stages(uint32_t m, uint32_t dstride, hipStream_t st) {
+        Work& l = ws;
         const int w_first = l.w_first, w_count = l.w_count;
         const uint32_t groups = l.groups;
         const uint32_t n_keys = groups * B;
-        const int nchunk = chunks_for(w_count, m);  // shadows the plan-wide value: this run's windows fill the chip
-        const uint32_t seg_len = pick_seg_len((uint64_t)w_count * m);  // shadows the plan-wide value likewise
+        const int nchunk = chunks_for(w_count, m);  // this run's windows fill the chip
+        const uint32_t seg_len = pick_seg_len((uint64_t)w_count * m);
         const uint32_t ch_len = (m + nchunk - 1) / nchunk;
-        int rc;
         ZK_HIP(hipEventRecord(l.ev_begin, st));
-        // general mode, small inputs: bucket-range partition (measured faster up to 2^18); otherwise the
-        // chunked counting sort with the XCD-aware scatter
+        // digit rows are stored relative to the plan's first window; the kernels index them with absolute windows
+        const uint16_t* d_dig = reinterpret_cast<const uint16_t*>(reinterpret_cast<uintptr_t>(this->d_dig) - (uintptr_t)pw_first * dstride * 2);
+        // general mode, small inputs: bucket-range partition (measured faster up to 2^18); otherwise the two-level sort
         const bool ranged = !pre && m < (1u << 19);
         const bool two_level = !ranged && l.tmp_ref != nullptr;
         if (two_level) {
@@ -1222,7 +1305,7 @@ struct MsmPlan : MsmPlanBase {
             {
                 const uint32_t NBP = (NB + 127) & ~127u;
                 const size_t lds_a = (size_t)SCATTER_TILE * 4 + (size_t)NBP * 12 + (size_t)SCATTER_TILE * 2;
-                hipLaunchKernelGGL(scatter_hi_staged_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), lds_a, st, d_dig, m, dstride, c, w_first, nchunk, ch8, fl, pre ? 1 : 0, (uint32_t)n, l.hist, l.tmp_ref);
+                hipLaunchKernelGGL(scatter_hi_staged_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), lds_a, st, d_dig, m, dstride, c, w_first, nchunk, ch8, fl, pre ? 1 : 0, (uint32_t)n, pw_first, l.hist, l.tmp_ref);
             }
             // LDS stage of level B: 1.5x the expected entries of a coarse bin, capped at 96 KiB
             uint64_t expect = ((uint64_t)w_count * m) / ((uint64_t)sets * NB);
@@ -1234,46 +1317,51 @@ struct MsmPlan : MsmPlanBase {
             hipLaunchKernelGGL(hist_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), B * 4, st, d_dig, m, dstride, c, w_first, nchunk, ch_len, l.hist);
             hipLaunchKernelGGL(prefix_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, l.hist, pre ? w_count * nchunk : nchunk, B, n_keys, l.total);
         }
-        if (!two_level && (rc = exclusive_scan(l, l.total, n_keys, l.bstart, st))) return rc;
-        ZK_HIP(hipMemsetAsync(l.big_count, 0, 8, st));
-        hipLaunchKernelGGL(runs_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, st, l.bstart, n_keys, seg_len, l.nseg, l.big_list, l.big_count);
-        if ((rc = exclusive_scan(l, l.nseg, n_keys, l.sstart, st))) return rc;
+        int rc;
+        if (!two_level && (rc = exclusive_scan(l.total, n_keys, l.bstart, st))) return rc;
+        {
+            // run offsets: run counts computed on the fly + three-launch scan
+            const uint32_t blocks = (n_keys + SCAN_BLOCK - 1) / SCAN_BLOCK;
+            hipLaunchKernelGGL(runs_scan_block_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, st, l.bstart, n_keys, seg_len, l.sstart, l.bsums, l.big_list, l.big_count);
+            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, l.bsums, blocks, l.grand);
+            hipLaunchKernelGGL(scan_add_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, st, l.sstart, n_keys, l.bsums, l.grand);
+        }
         if (two_level) {
             // already sorted
         } else if (ranged) {
             hipLaunchKernelGGL(scatter_range_kernel, dim3(w_count * (B >> range_log)), dim3(SORT_THREADS), (4u << range_log), st, d_dig, m, dstride, c, w_first, range_log, l.bstart, l.sorted);
         } else {
             const unsigned blocks = pre ? (unsigned)(w_count * nchunk) : (unsigned)(8 * ((w_count + 7) / 8) * nchunk);
-            hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(SORT_THREADS), B * 4, st, d_dig, m, dstride, c, w_first, w_count, nchunk, ch_len, pre ? 1 : 0, (uint32_t)n, l.hist, l.bstart, l.sorted);
+            hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(SORT_THREADS), B * 4, st, d_dig, m, dstride, c, w_first, w_count, nchunk, ch_len, pre ? 1 : 0, (uint32_t)n, pw_first, l.hist, l.bstart, l.sorted);
         }
-        // lanes are staggered: this lane's accumulation starts when the previous lane's has finished, so that the
-        // previous lane's low-occupancy reduction runs beside it (two accumulations side by side gain nothing)
-        if (after_acc) ZK_HIP(hipStreamWaitEvent(st, after_acc, 0));
         ZK_HIP(hipEventRecord(l.ev_acc0, st));
         // 5. accumulate
         uint64_t lanes_needed = ((uint64_t)w_count * m + seg_len - 1) / seg_len;
         hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((lanes_needed + 255) / 256)), dim3(256), 0, st, d_bases, l.sorted, l.bstart, l.sstart, n_keys, seg_len, l.partials, l.buckets);
         ZK_HIP(hipEventRecord(l.ev_acc1, st));
-        // 6. combine
-        hipLaunchKernelGGL(combine_kernel<G>, dim3((n_keys + 255) / 256), dim3(256), 0, st, l.partials, l.sstart, n_keys, l.buckets);
-        hipLaunchKernelGGL(combine_wave_kernel<G>, dim3(512), dim3(256), 0, st, l.partials, l.sstart, l.big_list, l.big_count, l.buckets);
-        hipLaunchKernelGGL(combine_big_kernel<G>, dim3(256), dim3(BIG_THREADS), 0, st, l.partials, l.sstart, l.big_list, n_keys, l.big_count, l.buckets);
+        // 6. combine (three tiers, one launch)
+        const uint32_t small_blocks = (2 * n_keys + COMBINE_THREADS - 1) / COMBINE_THREADS;
+        hipLaunchKernelGGL(combine_kernel<G>, dim3(small_blocks + COMBINE_WAVE_BLOCKS + COMBINE_BIG_BLOCKS), dim3(COMBINE_THREADS), 0, st,
+                           l.partials, l.sstart, n_keys, small_blocks, l.big_list, l.big_count, l.buckets);
         // 7. reduce: rows (sum over lo), cols (sum over hi), weighted sums
         uint32_t n_rows = groups * R, n_cols = groups * C;
         SumJob rows = {n_rows, R, B, C, 1u, C, 0u};
         SumJob cols = {n_cols, C, B, 1u, C, R, n_rows};
-        const uint32_t lpo = (n_rows + n_cols) >= 2048 ? 32u : 64u;  // measured: 8/16/32/64 -> 0.52/0.46/0.44/0.56 ms
+        // lanes per output (two lanes = one point): many outputs (one bucket set per window) -> 16 pairs each walk
+        // count/16 buckets and finish with a 4-level tree; few outputs (shared bucket set) -> 32 pairs, shortest chain
+        static const uint32_t lpo_env = getenv("ZKMI_LPO") ? (uint32_t)atoi(getenv("ZKMI_LPO")) : 0u;
+        const uint32_t lpo = lpo_env ? lpo_env : ((n_rows + n_cols) >= 2048 ? 32u : 64u);
         hipLaunchKernelGGL(strided_sum_kernel<G>, dim3(((n_rows + n_cols) * lpo + 255) / 256), dim3(256), 0, st, l.buckets, l.rows, rows, cols, lpo);
-        hipLaunchKernelGGL(weighted_sum_kernel<G>, dim3(2 * groups), dim3(HS_THREADS), 0, st, l.rows, R, groups,
-                           l.rows + (size_t)n_rows * XW, C, l.fin);
+        hipLaunchKernelGGL(weighted_sum_kernel<G>, dim3(groups * (bpr + bpc)), dim3(HS_THREADS), (size_t)HalfRegs<F>::COUNT * HS_THREADS * 4, st,
+                           l.rows, R, groups, l.rows + (size_t)n_rows * XW, C, l.fin);
         ZK_HIP(hipGetLastError());
-        ZK_HIP(hipMemcpyAsync(h_final + l.h_offset, l.fin, (size_t)groups * 4 * XW * 4, hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipMemcpyAsync(h_final, l.fin, (size_t)groups * (bpr + bpc) * 2 * XW * 4, hipMemcpyDeviceToHost, st));
         ZK_HIP(hipEventRecord(l.ev_done, st));
         return ZK_OK;
     }
 
     // state carried from enqueue() to finish()
-    int q_first = 0, q_count = 0, q_lanes = 0;
+    int q_first = 0, q_count = 0;
     uint32_t q_m = 0;
     hipStream_t q_stream = nullptr;
     bool q_pending = false;
@@ -1282,10 +1370,12 @@ struct MsmPlan : MsmPlanBase {
         std::lock_guard<std::mutex> lock(mu);
         if (q_pending) return fail(ZK_ERR_ARG, "MSM plan already has a run in flight: call zk_msm_plan_finish first");
         if (n_scalars > n) return fail(ZK_ERR_LENGTH, "Number of points and scalars mismatch");
-        if (w_count <= 0) { w_first = 0; w_count = nwin; }
-        if (w_first < 0 || w_first + w_count > nwin) return fail(ZK_ERR_ARG, "window range out of bounds");
+        if (w_count <= 0) { w_first = pw_first; w_count = pw_count; }
+        if (w_first < pw_first || w_first + w_count > pw_first + pw_count)
+            return fail(ZK_ERR_ARG, "window range out of bounds (the plan was created for windows [" + std::to_string(pw_first) + ", " +
+                                        std::to_string(pw_first + pw_count) + "))");
         const uint32_t m = (uint32_t)n_scalars;
-        q_first = w_first; q_count = w_count; q_m = m; q_stream = st; q_lanes = 0;
+        q_first = w_first; q_count = w_count; q_m = m; q_stream = st;
         if (m > 0) {
             const uint32_t* sc = (const uint32_t*)scalars;
             if (!on_device) {
@@ -1294,37 +1384,21 @@ struct MsmPlan : MsmPlanBase {
             }
             const uint32_t dstride = (m + 7u) & ~7u;
             ZK_HIP(hipEventRecord(ev_start, st));
-            // 1. digits (all windows, once)
+            // 1. digits (the windows of this run); digit rows are stored relative to the plan's first window
             DigitBias bias;
             memset(&bias, 0, sizeof(bias));
             for (int w = 0; w < nwin; ++w) {
                 int bit = w * c + (c - 1);
                 bias.v[bit >> 5] |= 1u << (bit & 31);
             }
-            hipLaunchKernelGGL(digits_kernel<FrP>, dim3((m + 255) / 256), dim3(256), 0, st, sc, m, dstride, c, w_first, w_count, bias, d_dig);
+            hipLaunchKernelGGL(digits_kernel<FrP>, dim3((m + 255) / 256), dim3(256), 0, st, sc, m, dstride, c, w_first, w_count, bias,
+                               reinterpret_cast<uint16_t*>(reinterpret_cast<uintptr_t>(d_dig) - (uintptr_t)pw_first * dstride * 2), ws.big_count);
             ZK_HIP(hipEventRecord(ev_digits, st));
-            // split the requested windows over the lanes (big problems only: small ones are latency-bound anyway)
-            int use = ((uint64_t)w_count * m >= (1ull << 22) && w_count >= 4) ? n_lanes : 1;
-            if (use > w_count) use = w_count;
-            q_lanes = use;
-            int first = w_first;
-            size_t h_off = 0;
-            for (int i = 0; i < use; ++i) {
-                Lane& l = lanes[i];
-                int cnt = w_count / use + (i < w_count % use ? 1 : 0);
-                l.w_first = first;
-                l.w_count = cnt;
-                l.groups = pre ? 1u : (uint32_t)cnt;
-                l.h_offset = h_off;
-                first += cnt;
-                h_off += (size_t)l.groups * 4 * XW;
-                hipStream_t ls = use == 1 ? st : l.stream;
-                if (use > 1) ZK_HIP(hipStreamWaitEvent(ls, ev_digits, 0));
-                int rc = run_lane(l, m, dstride, ls, i > 0 ? lanes[i - 1].ev_acc1 : nullptr);
-                if (rc) return rc;
-            }
-            // later work on the caller's stream is ordered after every lane
-            if (use > 1) for (int i = 0; i < use; ++i) ZK_HIP(hipStreamWaitEvent(st, lanes[i].ev_done, 0));
+            ws.w_first = w_first;
+            ws.w_count = w_count;
+            ws.groups = pre ? 1u : (uint32_t)w_count;
+            int rc = run_stages(m, dstride, st);
+            if (rc) return rc;
             ZK_HIP(hipEventRecord(ev_end, st));
         }
         q_pending = true;
@@ -1335,85 +1409,118 @@ struct MsmPlan : MsmPlanBase {
         std::lock_guard<std::mutex> lock(mu);
         if (!q_pending) return fail(ZK_ERR_ARG, "zk_msm_plan_finish without a pending run");
         q_pending = false;
-        XYZZ<F> total = xyzz_inf<F>();
+        typedef HostTail29<F> HF;
+        XYZZ<HF> total = xyzz_inf<HF>();
         if (q_m > 0) {
             ZK_HIP(hipEventSynchronize(ev_end));
-            // 8. host tail.  Per bucket set W = C * S_R + S_C + T (C = 2^lc).
-            //    general mode: total = sum_w 2^(c w) W_w by Horner from the top window down; the factor C rides along:
-            //        t <- 2^lc * (2^(c - lc) * t + S_R) + S_C + T  =  2^c t + W      (c doublings per window, not c + lc)
-            //    fixed-base mode: the sets are plain summands:  total = C * (sum S_R) + sum (S_C + T)
+            // 8. host tail.  Per bucket set, with row blocks (S_k, T_k), column blocks (S'_k, T'_k), C = 2^lc, WS_BLOCK = 2^7:
+            //        W = 2^(lc+7) X_R + 2^lc sum S_k + 2^7 X_C + (sum S'_k + sum T_k),   X = sum_k k T_k  (k = 1 at most)
+            //    general mode: total = sum_w 2^(c w) W_w by Horner from the top window down; the factors ride along the c
+            //    doublings between two windows, so a set costs c doublings whatever its block structure;
+            //    fixed-base mode: one set, the same chain.
             int lc = 0;
             while ((1u << lc) < C) ++lc;
+            const int groups = (int)ws.groups;
+            const uint32_t* rows_fin = h_final;
+            const uint32_t* cols_fin = h_final + (size_t)groups * bpr * 2 * XW;
+            auto pt = [](const uint32_t* p) { return HF::xyzz_from_device(p); };
             bool first_set = true;
-            XYZZ<F> rest = xyzz_inf<F>();
-            for (int li = q_lanes - 1; li >= 0; --li) {
-                const Lane& l = lanes[li];
-                const int groups = (int)l.groups;
-                for (int wl = groups - 1; wl >= 0; --wl) {
-                    const uint32_t* rowp = h_final + l.h_offset + (size_t)wl * 2 * XW;
-                    const uint32_t* colp = h_final + l.h_offset + ((size_t)groups * 2 + (size_t)wl * 2) * XW;
-                    XYZZ<F> sr = load_xyzz_host<F>(rowp), tot = load_xyzz_host<F>(rowp + XW), scol = load_xyzz_host<F>(colp);
-                    if (pre) {
-                        total = xyzz_add<F>(total, sr);
-                        rest = xyzz_add<F>(rest, xyzz_add<F>(scol, tot));
-                    } else {
-                        if (!first_set) for (int k = 0; k < c - lc; ++k) total = xyzz_dbl<F>(total);
-                        total = xyzz_add<F>(total, sr);
-                        for (int k = 0; k < lc; ++k) total = xyzz_dbl<F>(total);
-                        total = xyzz_add<F>(total, xyzz_add<F>(scol, tot));
-                    }
-                    first_set = false;
+            for (int g = groups - 1; g >= 0; --g) {
+                XYZZ<HF> sum_s = xyzz_inf<HF>(), sum_t = xyzz_inf<HF>(), x_r = xyzz_inf<HF>();
+                for (uint32_t k = 0; k < bpr; ++k) {
+                    const uint32_t* q = rows_fin + ((size_t)g * bpr + k) * 2 * XW;
+                    sum_s = xyzz_add<HF>(sum_s, pt(q));
+                    XYZZ<HF> t = pt(q + XW);
+                    sum_t = xyzz_add<HF>(sum_t, t);
+                    for (uint32_t j = 0; j < k; ++j) x_r = xyzz_add<HF>(x_r, t);  // k T_k, k <= 1 in practice
                 }
+                XYZZ<HF> sum_sc = xyzz_inf<HF>(), x_c = xyzz_inf<HF>();
+                for (uint32_t k = 0; k < bpc; ++k) {
+                    const uint32_t* q = cols_fin + ((size_t)g * bpc + k) * 2 * XW;
+                    sum_sc = xyzz_add<HF>(sum_sc, pt(q));
+                    if (k) {
+                        XYZZ<HF> t = pt(q + XW);
+                        for (uint32_t j = 0; j < k; ++j) x_c = xyzz_add<HF>(x_c, t);
+                    }
+                }
+                // terms in descending order of their exponent; `at` = exponent the accumulator currently sits at
+                int at = first_set ? -1 : c;
+                auto step = [&](int exp, const XYZZ<HF>& term, bool present) {
+                    if (!present) return;
+                    if (at >= 0) for (int k = 0; k < at - exp; ++k) total = xyzz_dbl<HF>(total);
+                    total = xyzz_add<HF>(total, term);
+                    at = exp;
+                };
+                if (bpr > 1 && lc + WS_BLOCK_LOG > c && !first_set) return fail(ZK_ERR_ARG, "internal: reduction layout does not fit the window");
+                step(lc + WS_BLOCK_LOG, x_r, bpr > 1);
+                step(lc, sum_s, true);
+                step(WS_BLOCK_LOG, x_c, bpc > 1);
+                step(0, xyzz_add<HF>(sum_sc, sum_t), true);
+                first_set = false;
             }
-            if (pre) {
-                for (int k = 0; k < lc; ++k) total = xyzz_dbl<F>(total);
-                total = xyzz_add<F>(total, rest);
-            } else {
-                for (int k = 0; k < c * q_first; ++k) total = xyzz_dbl<F>(total);
-            }
+            if (!pre) for (int k = 0; k < c * q_first; ++k) total = xyzz_dbl<HF>(total);
             float sort_ms = 0, acc_ms = 0, red_ms = 0, t = 0;
-            for (int li = 0; li < q_lanes; ++li) {
-                const Lane& l = lanes[li];
-                if (hipEventElapsedTime(&t, l.ev_begin, l.ev_acc0) == hipSuccess) sort_ms += t;
-                if (hipEventElapsedTime(&t, l.ev_acc0, l.ev_acc1) == hipSuccess) acc_ms += t;
-                if (hipEventElapsedTime(&t, l.ev_acc1, l.ev_done) == hipSuccess) red_ms += t;
-            }
+            if (hipEventElapsedTime(&t, ws.ev_begin, ws.ev_acc0) == hipSuccess) sort_ms += t;
+            if (hipEventElapsedTime(&t, ws.ev_acc0, ws.ev_acc1) == hipSuccess) acc_ms += t;
+            if (hipEventElapsedTime(&t, ws.ev_acc1, ws.ev_done) == hipSuccess) red_ms += t;
             if (hipEventElapsedTime(&t, ev_start, ev_digits) == hipSuccess) sort_ms += t;
-            timings[0] = sort_ms;   // digits + sort, summed over lanes
-            timings[1] = acc_ms;    // accumulate kernel launches, summed over lanes
-            timings[2] = red_ms;    // combine + reduction + D2H, summed over lanes (lanes overlap each other)
+            timings[0] = sort_ms;   // digits + sort
+            timings[1] = acc_ms;    // accumulate kernel
+            timings[2] = red_ms;    // combine + reduction + D2H
+        }
+        HF::affine_to_canonical(xyzz_to_affine<HF>(total), out);
+        if (q_m > 0) {
+            float t = 0;
             ZK_HIP(hipEventRecord(ev_digits, q_stream));  // reuse as "host tail done" marker
             ZK_HIP(hipEventSynchronize(ev_digits));
             (void)hipEventElapsedTime(&timings[3], ev_end, ev_digits);
             (void)hipEventElapsedTime(&timings[4], ev_start, ev_digits);
+            (void)t;
         }
-        Affine<F> a = xyzz_to_affine<F>(total);
-        uint32_t w[AW];
-        F::to_canonical(w, a.x);
-        F::to_canonical(w + F::LIMBS, a.y);
-        memcpy(out, w, sizeof(w));
         return ZK_OK;
     }
 };
+
+// batch_multi_scalar_g1/_g2: out[i] = k_i * P_i (canonical affine).  One base for many scalars (what Groth16.setup
+// does) goes through the fixed-base table: <= 16 mixed additions per scalar; everything ends in the batched normalisation.
+constexpr uint64_t FIXED_BASE_MIN = 2048;  // below this the table (2^19 rows) costs more than it saves
 
 template <class G>
 static int batch_mul_impl(uint64_t n, const uint64_t* scalars, const uint64_t* bases, int broadcast, uint64_t* out) {
     typedef typename G::F F;
     typedef typename G::Fr FrP;
-    constexpr int AW = 2 * F::LIMBS;
+    constexpr int AW = 2 * F::LIMBS, XW = 4 * F::LIMBS;
     if (n == 0) return ZK_OK;
-    uint32_t *ds = nullptr, *db = nullptr, *dout = nullptr;
+    uint32_t *ds = nullptr, *db = nullptr, *dout = nullptr, *temp = nullptr;
     int rc = ZK_OK;
+    const bool fixed = broadcast && n >= FIXED_BASE_MIN;
     uint64_t nb = broadcast ? 1 : n;
     ZK_HIP(hipMalloc(&ds, n * FrP::W * 4));
     do {
-        if (hipMalloc(&db, nb * AW * 4) != hipSuccess || hipMalloc(&dout, n * AW * 4) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMalloc failed"); break; }
-        if (hipMemcpy(ds, scalars, n * FrP::W * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(db, bases, nb * AW * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy H2D failed"); break; }
-        hipLaunchKernelGGL(batch_mul_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, ds, db, broadcast, n, dout);
+        if (hipMalloc(&temp, n * XW * 4) != hipSuccess || hipMalloc(&dout, n * AW * 4) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMalloc failed"); break; }
+        if (hipMemcpy(ds, scalars, n * FrP::W * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy H2D failed"); break; }
+        if (fixed) {
+            FixedTable<G>& ft = FixedTable<G>::get();
+            std::lock_guard<std::mutex> lock(ft.mu);
+            if ((rc = ft.ensure(bases))) break;
+            FixedBias bias;
+            memset(&bias, 0, sizeof(bias));
+            for (int j = 0; j < ft.nwin; ++j) {
+                int bit = j * FIXED_C + (FIXED_C - 1);
+                bias.v[bit >> 5] |= 1u << (bit & 31);
+            }
+            hipLaunchKernelGGL(fixed_mul_kernel<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ds, n, ft.d_table, ft.nwin, bias, temp);
+            if (hipDeviceSynchronize() != hipSuccess) { rc = fail(ZK_ERR_HIP, "fixed-base multiplication kernel failed"); break; }
+        } else {
+            if (hipMalloc(&db, nb * AW * 4) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMalloc failed"); break; }
+            if (hipMemcpy(db, bases, nb * AW * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy H2D failed"); break; }
+            hipLaunchKernelGGL(varbase_mul_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, ds, db, broadcast, n, temp);
+        }
+        hipLaunchKernelGGL(normalize_kernel<G>, dim3((unsigned)((n + (uint64_t)NORM_THREADS * NORM_E - 1) / ((uint64_t)NORM_THREADS * NORM_E))),
+                           dim3(NORM_THREADS), 0, 0, temp, n, dout, 1);
         if (hipGetLastError() != hipSuccess || hipMemcpy(out, dout, n * AW * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "batch_mul kernel / D2H failed"); break; }
     } while (0);
-    (void)hipFree(ds); (void)hipFree(db); (void)hipFree(dout);
+    (void)hipFree(ds); (void)hipFree(db); (void)hipFree(dout); (void)hipFree(temp);
     return rc;
 }
 

@@ -28,8 +28,10 @@ struct MsmPlanBase {
 
 // factories implemented in msm_group.hip (one object file per group)
 #define ZK_DECLARE_GROUP(G)                                                                                              \
-    int msm_plan_create_##G(uint64_t n, const void* bases, int on_device, int flags, int window_bits, MsmPlanBase** out); \
-    int msm_batch_mul_##G(uint64_t n, const uint64_t* scalars, const uint64_t* bases, int broadcast, uint64_t* out);
+    int msm_plan_create_##G(uint64_t n, const void* bases, int on_device, int flags, int window_bits, int window_first,    \
+                            int window_count, MsmPlanBase** out);                                                        \
+    int msm_batch_mul_##G(uint64_t n, const uint64_t* scalars, const uint64_t* bases, int broadcast, uint64_t* out);     \
+    void msm_fixed_table_free_##G();
 ZK_DECLARE_GROUP(Bn254G1)
 ZK_DECLARE_GROUP(Bn254G2)
 ZK_DECLARE_GROUP(Bls381G1)

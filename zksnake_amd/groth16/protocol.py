@@ -116,12 +116,12 @@ class Groth16:
         import torch.distributed as dist
         self._shard = (dist.get_rank(), dist.get_world_size(), device)
 
-    def _enqueue_msm(self, bases, group, d_scalars, count, slot=0):
+    def _enqueue_msm(self, bases, group, d_scalars, count, slot=0, high_priority=False):
         """start <bases[:count], scalars> (scalars already in HBM) on the plan's own stream; with sharding only
         this rank's windows.  Returns (array, handle); handle None = this rank has no window of that MSM."""
         lib = N.load()
         arr = _as_array(self.E, bases, group)
-        handle = arr.plan(slot, precompute=self.precompute_keys)
+        handle = arr.plan(slot, precompute=self.precompute_keys, high_priority=high_priority)
         first, cnt = 0, 0  # 0, 0 = all windows
         if self._shard is not None and self._shard[1] > 1:
             from ..parallel import window_ranges
@@ -159,10 +159,12 @@ class Groth16:
 
     def prove(self, public_witness, private_witness) -> Proof:
         """public_witness / private_witness: lists of ints (reference API) or (k, 4) uint64 limb arrays."""
+        import time
         assert self.proving_key, "ProvingKey has not been generated"
         pk = self.proving_key
         assert len(pk.kdelta_1) == len(private_witness), "Length of kdelta_1 and private_witness must be equal"
         q = self.order
+        t_start = time.perf_counter()
         if self._blinding is not None:
             r, s = self._blinding
         else:
@@ -179,31 +181,52 @@ class Groth16:
             witness = (pub, prv)
         else:
             witness = list(public_witness) + list(private_witness)
-        try:
-            res = self.qap.evaluate_witness_device(witness)
-        except ValueError as exc:
-            raise ValueError("Failed to evaluate with the given witness") from exc
-
-        n = res.n
         n_pub = self.qap.n_public
         n_priv = len(private_witness)
-        # all five MSMs are put in flight on their plans' own streams, then collected: the latency-bound
-        # bucket reductions of one overlap with the accumulation kernels of the others
+        early = {}
+
+        def start_witness_msm(d_witness):
+            # <kdelta_1, w_priv> needs the witness only: it starts on its plan's stream as soon as the witness is in
+            # HBM and runs beside the QAP transform chain
+            if n_priv > 0:
+                pk.kdelta_1, early["k"] = self._enqueue_msm(pk.kdelta_1, 1, d_witness.ptr + 32 * n_pub, n_priv)
+
+        try:
+            res = self.qap.evaluate_witness_device(witness, after_upload=start_witness_msm)
+        except ValueError as exc:
+            if early.get("k") is not None:  # drain the run in flight: the plan accepts one at a time
+                self._finish_msm(early["k"], 1)
+            raise ValueError("Failed to evaluate with the given witness") from exc
+
+        t_qap = time.perf_counter()
+        n = res.n
+        # the four MSMs over u, v, h are put in flight on their plans' own streams, then collected: the latency-bound
+        # bucket reductions of one overlap with the accumulation kernels of the others.  The G2 MSM (three times the
+        # work of a G1 one, and the longest reduction tail) goes first, on a high-priority stream.
+        pk.tau_2, h_v2 = self._enqueue_msm(pk.tau_2, 2, res.v.ptr, min(n, len(pk.tau_2)), high_priority=True)
         pk.tau_1, h_u = self._enqueue_msm(pk.tau_1, 1, res.u.ptr, min(n, len(pk.tau_1)), slot=0)
-        pk.tau_2, h_v2 = self._enqueue_msm(pk.tau_2, 2, res.v.ptr, min(n, len(pk.tau_2)))
         pk.tau_1, h_v1 = self._enqueue_msm(pk.tau_1, 1, res.v.ptr, min(n, len(pk.tau_1)), slot=1)
         pk.target_1, h_h = self._enqueue_msm(pk.target_1, 1, res.h.ptr, min(n, len(pk.target_1)))
-        h_k = None
-        if n_priv > 0:
-            pk.kdelta_1, h_k = self._enqueue_msm(pk.kdelta_1, 1, res.witness.ptr + 32 * n_pub, n_priv)
+        h_k = early.get("k")
+        t_enq = time.perf_counter()
+        # the blinding terms depend on the key and (r, s) only: the host computes them (four scalar multiplications,
+        # ~1 ms) while the GPU works through the MSMs, instead of after them
+        a_fixed = pk.alpha_1 + pk.delta_1 * r
+        b1_fixed = pk.beta_1 + pk.delta_1 * s
+        b2_fixed = pk.beta_2 + pk.delta_2 * s
+        c_fixed = (-pk.delta_1) * (r * s % q)
         parts = [(self._finish_msm(h_u, 1), 1), (self._finish_msm(h_v2, 2), 2), (self._finish_msm(h_v1, 1), 1),
                  (self._finish_msm(h_h, 1), 1), (self._finish_msm(h_k, 1), 1)]
+        t_fin = time.perf_counter()
         msm_u, msm_v2, msm_v1, HZ, sum_delta_witness = self._exchange(parts)
 
-        A = msm_u + pk.alpha_1 + pk.delta_1 * r
-        B1 = msm_v1 + pk.beta_1 + pk.delta_1 * s
-        B2 = msm_v2 + pk.beta_2 + pk.delta_2 * s
-        C = HZ + sum_delta_witness + A * s + B1 * r + (-pk.delta_1) * (r * s % q)
+        A = msm_u + a_fixed
+        B1 = msm_v1 + b1_fixed
+        B2 = msm_v2 + b2_fixed
+        C = HZ + sum_delta_witness + A * s + B1 * r + c_fixed
+        t_end = time.perf_counter()
+        self.last_timings = {"qap_ms": (t_qap - t_start) * 1e3, "msm_enqueue_ms": (t_enq - t_qap) * 1e3,
+                             "msm_finish_ms": (t_fin - t_enq) * 1e3, "exchange_assemble_ms": (t_end - t_fin) * 1e3}
         return Proof(A, B2, C)
 
     # ------------------------------------------------------------------------------------------

@@ -38,6 +38,7 @@ class QAP:
         self.p = p or BN254_SCALAR_FIELD
         self._dev = None
         self._ws = None
+        self._stream = None
 
     def from_r1cs(self, r1cs):
         assert r1cs.A is not None, "R1CS is not compiled"
@@ -72,10 +73,20 @@ class QAP:
                                   c=DeviceBuffer(n * eb), h=DeviceBuffer(n * eb), work=DeviceBuffer(4 * n * eb)))
         return self._ws[1]
 
-    def evaluate_witness_device(self, witness) -> DeviceQapResult:
+    def _qap_stream(self):
+        """the QAP chain runs on a stream of its own (non-blocking w.r.t. the default stream), so that an MSM that
+        only needs the witness can run beside it on its plan's stream"""
+        if self._stream is None:
+            st = N._vp()
+            N.check(N.ensure_gpu().zk_stream_create(0, N.ctypes.byref(st)))
+            self._stream = st
+        return self._stream
+
+    def evaluate_witness_device(self, witness, after_upload=None) -> DeviceQapResult:
         """witness: list of ints or (n_col, 4) uint64 limbs.  Raises ValueError when the witness does
         not satisfy the constraints (non-zero remainder), like the reference.  The returned buffers belong
-        to this QAP object and are overwritten by the next call."""
+        to this QAP object and are overwritten by the next call.  `after_upload(witness_buffer)` is called once the
+        canonical witness is resident in HBM, before the transform chain is enqueued."""
         lib = N.ensure_gpu()
         cid = self._curve_id()
         n = self.a.n_row
@@ -93,6 +104,7 @@ class QAP:
         if sum(p.shape[0] for p in parts) != self.a.n_col:
             raise ValueError("witness length does not match the number of R1CS columns")
         ws = self._workspace(n, self.a.n_col)
+        st = self._qap_stream()
         off = 0
         for part in parts:
             if part.shape[0]:
@@ -100,11 +112,14 @@ class QAP:
             off += part.nbytes
         if any(isinstance(x, np.ndarray) for x in (witness if isinstance(witness, tuple) else (witness,))):
             # int lists were reduced mod r on the host (Fr::from); limb arrays are reduced here, one cheap pass
-            N.check(lib.zk_vec_canon_dev(cid, self.a.n_col, ws["w"].ptr, None))
+            N.check(lib.zk_vec_canon_dev(cid, self.a.n_col, ws["w"].ptr, st))
+            N.check(lib.zk_stream_synchronize(st))
+        if after_upload is not None:
+            after_upload(ws["w"])
         for (rp, cl, vl), dst in zip(self._device_matrices(), (ws["a"], ws["b"], ws["c"])):
-            N.check(lib.zk_spmv_dev(cid, n, rp.ptr, cl.ptr, vl.ptr, ws["w"].ptr, dst.ptr, None))
+            N.check(lib.zk_spmv_dev(cid, n, rp.ptr, cl.ptr, vl.ptr, ws["w"].ptr, dst.ptr, st))
         ok = N._i(0)
-        N.check(lib.zk_qap_h_dev(cid, log_n, ws["a"].ptr, ws["b"].ptr, ws["c"].ptr, ws["h"].ptr, ws["work"].ptr, ok, None))
+        N.check(lib.zk_qap_h_dev(cid, log_n, ws["a"].ptr, ws["b"].ptr, ws["c"].ptr, ws["h"].ptr, ws["work"].ptr, ok, st))
         if not ok.value:
             raise ValueError("(U * V - W) did not divided by Z to zero")
         return DeviceQapResult(n, ws["a"], ws["b"], ws["h"], ws["w"])
