@@ -96,11 +96,18 @@ int zk_vec_op_dev(int curve, int op, uint64_t n, const void* d_a, const void* d_
  * witnesses handed to the device-resident provers are only ASSUMED canonical by the kernels behind them. */
 int zk_vec_canon_dev(int curve, uint64_t n, void* d_x, void* stream);
 
-/* SparseArray.dot (python/zksnake/array.py:36-44) as a CSR sparse matrix-vector product over Fr:
- * out[row] = sum_k vals[k] * w[cols[k]] for k in [row_ptr[row], row_ptr[row+1]).  vals / w / out are
- * canonical Fr vectors in device memory; row_ptr (n_rows+1) and cols are uint32 device arrays. */
+/* SparseArray.dot (python/zksnake/array.py:36-44) as a CSR product over Fr on device-resident arrays:
+ * row_ptr u32[n_rows + 1], cols u32[nnz], vals canonical Fr[nnz], w canonical Fr[n_cols] (cols must be < n_cols: the
+ * host validates, SparseArray.to_csr), out canonical Fr[n_rows].  One lane per row; rows with more than
+ * skip_longer_than entries (0 = never) are left untouched for zk_spmv_long_dev. */
 int zk_spmv_dev(int curve, uint64_t n_rows, const void* d_row_ptr, const void* d_cols, const void* d_vals,
-                const void* d_w, void* d_out, void* stream);
+                const void* d_w, void* d_out, uint32_t skip_longer_than, void* stream);
+/* The long rows of the same product: long_rows u32[n_long] (row indices), item_ptr u32[n_long + 1] into
+ * items, items u32[n_items][2] = entry ranges [k0, k1) of at most a few thousand entries each (the host cuts the rows
+ * once per matrix), partials = scratch of n_items Fr elements.  One workgroup per item, then one per long row. */
+int zk_spmv_long_dev(int curve, uint64_t n_long, const void* d_long_rows, const void* d_item_ptr, uint64_t n_items,
+                     const void* d_items, const void* d_cols, const void* d_vals, const void* d_w, void* d_partials,
+                     void* d_out, void* stream);
 
 /* Fused QAP.evaluate_witness tail (python/zksnake/groth16/qap.py:57-69): from the evaluation vectors
  * a = A.w, b = B.w, c = C.w (2^log_n canonical Fr elements each, device memory) compute in place the

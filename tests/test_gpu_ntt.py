@@ -163,5 +163,41 @@ def test_spmv(gpu, name, cid):
     rp, cl, vl = m.to_csr()
     bufs = [DeviceBuffer.from_numpy(x) for x in (rp, cl, vl, N.ints_to_limbs(w))]
     out = DeviceBuffer(n_row * 32)
-    N.check(gpu.zk_spmv_dev(cid, n_row, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, out.ptr, None))
+    N.check(gpu.zk_spmv_dev(cid, n_row, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, out.ptr, 0, None))
     assert N.limbs_to_ints(out.download((n_row, 4))) == m.dot(w) == pyref.sparse_dot(trip, n_row, w, cv.r)
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+def test_spmv_long_rows(gpu, name, cid):
+    """rows far beyond the lane-per-row limit (the constant-one wire / input wires of a transposed R1CS): one row with
+    10000 entries (three work items), one with 65 (just over the limit), one with 64 (just under), empty rows, against
+    SparseArray.dot; then the transpose used by Groth16.setup"""
+    import random
+    from zksnake_amd.array import SparseArray
+    from zksnake_amd.device import DeviceBuffer
+    from zksnake_amd.spmv import ITEM, LONG_ROW, DeviceCsr
+    cv = pyref.curve_by_name(name)
+    rnd = random.Random(11)
+    n_row, n_col = 9, 12000
+    trip = [(0, c, rnd.randrange(cv.r)) for c in range(10000)]
+    trip += [(3, rnd.randrange(n_col), rnd.randrange(cv.r)) for _ in range(LONG_ROW + 1)]
+    trip += [(5, rnd.randrange(n_col), rnd.randrange(cv.r)) for _ in range(LONG_ROW)]
+    trip += [(7, 1, cv.r - 1), (7, 0, 5)]
+    rnd.shuffle(trip)
+    m = SparseArray.from_triplets(*zip(*trip), n_row, n_col, cv.r)
+    w = [rnd.randrange(cv.r) for _ in range(n_col)]
+    csr = DeviceCsr(cid, *m.to_csr())
+    assert csr.n_long == 2 and csr.n_items == -(-10000 // ITEM) + 1
+    dw, out = DeviceBuffer.from_numpy(N.ints_to_limbs(w)), DeviceBuffer(n_row * 32)
+    out.upload(np.full((n_row, 4), 7, dtype=np.uint64))            # stale data must not survive in empty rows
+    csr.apply(dw.ptr, out.ptr)
+    assert N.limbs_to_ints(out.download((n_row, 4))) == m.dot(w)
+    # transpose: 12000 rows of 0..2 entries each
+    x = [rnd.randrange(cv.r) for _ in range(n_row)]
+    csc = DeviceCsr(cid, *m.to_csc())
+    dx, out_t = DeviceBuffer.from_numpy(N.ints_to_limbs(x)), DeviceBuffer(n_col * 32)
+    csc.apply(dx.ptr, out_t.ptr)
+    exp = [0] * n_col
+    for r, c, v in trip:
+        exp[c] = (exp[c] + v * x[r]) % cv.r
+    assert N.limbs_to_ints(out_t.download((n_col, 4))) == exp

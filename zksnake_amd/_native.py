@@ -54,7 +54,8 @@ SIGNATURES = {
     "zk_stream_create": (_i, [_i, ctypes.POINTER(_vp)]),
     "zk_stream_destroy": (_i, [_vp]),
     "zk_stream_synchronize": (_i, [_vp]),
-    "zk_spmv_dev": (_i, [_i, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "zk_spmv_dev": (_i, [_i, _u64, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint32, _vp]),
+    "zk_spmv_long_dev": (_i, [_i, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "zk_fq_limbs": (_i, [_i]),
     "zk_point_limbs": (_i, [_i, _i]),
     "zk_ntt": (_i, [_i, _i, _i, _u64, _u64p, _u64, _u64p]),

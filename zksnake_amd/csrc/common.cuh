@@ -6,6 +6,7 @@
 #include <string>
 #include "../../include/zkmi.h"
 #include "curve.cuh"
+#include "host64.cuh"
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -40,24 +41,28 @@ inline int fail(int code, const std::string& msg) {
 
 struct Bn254G1 {
     typedef FpOps<BnFqParams> F;
+    typedef HostTail64<Fp64Ops<BnFqParams>> HostF;  // 64-bit-limb host arithmetic (host64.cuh)
     typedef BnFrParams Fr;
     static constexpr int CURVE = ZK_CURVE_BN254, GROUP = ZK_G1;
     static constexpr int FQ64 = 4;  // 64-bit limbs per base field element
 };
 struct Bn254G2 {
     typedef Fp2Ops<BnFqParams> F;
+    typedef HostTail64<Fp2Ops64<BnFqParams>> HostF;
     typedef BnFrParams Fr;
     static constexpr int CURVE = ZK_CURVE_BN254, GROUP = ZK_G2;
     static constexpr int FQ64 = 4;
 };
 struct Bls381G1 {
     typedef FpOps<BlsFqParams> F;
+    typedef HostTail64<Fp64Ops<BlsFqParams>> HostF;
     typedef BlsFrParams Fr;
     static constexpr int CURVE = ZK_CURVE_BLS12_381, GROUP = ZK_G1;
     static constexpr int FQ64 = 6;
 };
 struct Bls381G2 {
     typedef Fp2Ops<BlsFqParams> F;
+    typedef HostTail64<Fp2Ops64<BlsFqParams>> HostF;
     typedef BlsFrParams Fr;
     static constexpr int CURVE = ZK_CURVE_BLS12_381, GROUP = ZK_G2;
     static constexpr int FQ64 = 6;

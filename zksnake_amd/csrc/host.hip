@@ -40,6 +40,19 @@ static void store_point(uint64_t* dst, const Affine<typename G::F>& p) {
     F::to_canonical(w + F::LIMBS, p.y);
 }
 
+// the same on the 64-bit-limb host arithmetic (host64.cuh): add / sum / scalar multiplication of single points, what a
+// proof's assembly spends its host time on (~20 operations per proof, python/zksnake/groth16/protocol.py:133-163)
+template <class G>
+static Affine<typename G::HostF> load_point64(const uint64_t* src) {
+    typedef typename G::HostF HF;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(src);
+    return {HF::from_canonical(w), HF::from_canonical(w + HF::LIMBS)};
+}
+template <class G>
+static void store_point64(uint64_t* dst, const Affine<typename G::HostF>& p) {
+    G::HostF::affine_to_canonical(p, dst);
+}
+
 template <class G>
 static bool point_on_curve(const Affine<typename G::F>& p) {
     typedef typename G::F F;
@@ -428,10 +441,10 @@ int zk_point_bytes(int curve, int group) {
 int zk_point_add(int curve, int group, const uint64_t* a, const uint64_t* b, uint64_t* out) {
 #define CALL(G)                                                              \
     {                                                                        \
-        typedef G::F F;                                                      \
-        XYZZ<F> acc = xyzz_from_affine<F>(load_point<G>(a));                 \
-        xyzz_add_affine<F>(acc, load_point<G>(b));                           \
-        store_point<G>(out, xyzz_to_affine<F>(acc));                         \
+        typedef G::HostF F;                                                  \
+        XYZZ<F> acc = xyzz_from_affine<F>(load_point64<G>(a));               \
+        xyzz_add_affine<F>(acc, load_point64<G>(b));                         \
+        store_point64<G>(out, xyzz_to_affine<F>(acc));                       \
         return ZK_OK;                                                        \
     }
     ZK_DISPATCH_GROUP(curve, group, CALL);
@@ -441,11 +454,11 @@ int zk_point_add(int curve, int group, const uint64_t* a, const uint64_t* b, uin
 int zk_point_sum(int curve, int group, uint64_t n, const uint64_t* points, uint64_t* out) {
 #define CALL(G)                                                              \
     {                                                                        \
-        typedef G::F F;                                                      \
-        const size_t stride = F::LIMBS;  /* 64-bit limbs per affine point */    \
+        typedef G::HostF F;                                                  \
+        const size_t stride = G::F::LIMBS;  /* 64-bit limbs per affine point */ \
         XYZZ<F> acc = xyzz_inf<F>();                                         \
-        for (uint64_t i = 0; i < n; ++i) xyzz_add_affine<F>(acc, load_point<G>(points + i * stride)); \
-        store_point<G>(out, xyzz_to_affine<F>(acc));                         \
+        for (uint64_t i = 0; i < n; ++i) xyzz_add_affine<F>(acc, load_point64<G>(points + i * stride)); \
+        store_point64<G>(out, xyzz_to_affine<F>(acc));                       \
         return ZK_OK;                                                        \
     }
     ZK_DISPATCH_GROUP(curve, group, CALL);
@@ -466,11 +479,11 @@ int zk_point_neg(int curve, int group, const uint64_t* a, uint64_t* out) {
 int zk_point_mul(int curve, int group, const uint64_t* a, const uint64_t* scalar, uint64_t* out) {
 #define CALL(G)                                                              \
     {                                                                        \
-        typedef G::F F;                                                      \
+        typedef G::HostF F;                                                  \
         uint32_t k[G::Fr::W];                                                \
         reduce_scalar<G::Fr>(k, scalar);                                     \
-        XYZZ<F> r = xyzz_scalar_mul<F>(load_point<G>(a), k, G::Fr::W);       \
-        store_point<G>(out, xyzz_to_affine<F>(r));                           \
+        XYZZ<F> r = xyzz_scalar_mul<F>(load_point64<G>(a), k, G::Fr::W);     \
+        store_point64<G>(out, xyzz_to_affine<F>(r));                         \
         return ZK_OK;                                                        \
     }
     ZK_DISPATCH_GROUP(curve, group, CALL);

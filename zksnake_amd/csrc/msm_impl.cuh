@@ -1063,20 +1063,6 @@ struct FixedTable {
     }
 };
 
-// host-side facade of the tail: the device field facade plus the two conversions the tail needs
-template <class F>
-struct HostTail29 : F {
-    static XYZZ<HostTail29> xyzz_from_device(const uint32_t* w) {
-        return {F::load(w), F::load(w + F::LIMBS), F::load(w + 2 * F::LIMBS), F::load(w + 3 * F::LIMBS)};
-    }
-    static void affine_to_canonical(const Affine<HostTail29>& a, uint64_t* out) {
-        uint32_t w[2 * F::LIMBS];
-        F::to_canonical(w, a.x);
-        F::to_canonical(w + F::LIMBS, a.y);
-        memcpy(out, w, sizeof(w));
-    }
-};
-
 template <class G>
 struct MsmPlan : MsmPlanBase {
     typedef typename G::F F;
@@ -1409,7 +1395,7 @@ struct MsmPlan : MsmPlanBase {
         std::lock_guard<std::mutex> lock(mu);
         if (!q_pending) return fail(ZK_ERR_ARG, "zk_msm_plan_finish without a pending run");
         q_pending = false;
-        typedef HostTail29<F> HF;
+        typedef typename G::HostF HF;  // 64-bit-limb host arithmetic for the sequential tail (host64.cuh)
         XYZZ<HF> total = xyzz_inf<HF>();
         if (q_m > 0) {
             ZK_HIP(hipEventSynchronize(ev_end));

@@ -175,21 +175,78 @@ __global__ void div_vanishing_kernel(uint64_t n, uint64_t len, const uint32_t* c
     }
 }
 
-// CSR sparse matrix-vector product over Fr, one lane per row: out[row] = sum vals[k] * w[cols[k]].
+// CSR sparse matrix-vector product over Fr: out[row] = sum vals[k] * w[cols[k]].
 // Canonical in/out: mont(mont(v, x), R^2) = v*x; the sum is accumulated in Montgomery-by-R^-1 form
 // and fixed up once per row.
+// Short rows (the bulk of an R1CS) take one lane each.  A row longer than `skip_longer_than` is left to the long-row
+// kernels below: the constant-one wire and the input wires of a real circuit (and every row of the transposed matrices
+// that Groth16.setup multiplies) can hold 2^20 entries, and one lane walking them took 0.8 s.
 template <class P>
 __global__ void spmv_kernel(uint64_t n_rows, const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ cols,
-                            const uint32_t* __restrict__ vals, const uint32_t* __restrict__ w, uint32_t* __restrict__ out) {
+                            const uint32_t* __restrict__ vals, const uint32_t* __restrict__ w, uint32_t* __restrict__ out,
+                            uint32_t skip_longer_than) {
     uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
+    const uint32_t k0 = row_ptr[row], k1 = row_ptr[row + 1];
+    if (skip_longer_than && k1 - k0 > skip_longer_than) return;
     Fp<P> acc = fp_zero<P>();
-    for (uint32_t k = row_ptr[row]; k < row_ptr[row + 1]; ++k) {
+    for (uint32_t k = k0; k < k1; ++k) {
         Fp<P> v = load_fr<P>(vals + (size_t)k * P::W);
         Fp<P> x = load_fr<P>(w + (size_t)cols[k] * P::W);
         acc = fp_add<P>(acc, fp_mul<P>(v, x));  // v*x/R
     }
     store_fr<P>(out + row * P::W, fp_reduce_full<P>(fp_mul<P>(acc, fp_const<P>(P::R2))));
+}
+
+// Long rows, two launches and no cross-workgroup hand-off: the host cuts every long row into work items [k0, k1) of at
+// most a few thousand entries (static per matrix); one workgroup per item leaves its partial sum (still v*x/R form,
+// semi-reduced) in `partials`; one workgroup per long row then adds up its items and writes the canonical result.
+constexpr int SPMV_LONG_THREADS = 256;
+
+template <class P>
+__device__ __forceinline__ Fp<P> block_sum_fr(Fp<P> acc, uint32_t* sh) {
+    constexpr int N = P::N;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t off = SPMV_LONG_THREADS / 2; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int l = 0; l < N; ++l) sh[l * SPMV_LONG_THREADS + tid] = acc.v[l];
+        __syncthreads();
+        if (tid < off) {
+            Fp<P> o;
+#pragma unroll
+            for (int l = 0; l < N; ++l) o.v[l] = sh[l * SPMV_LONG_THREADS + tid + off];
+            acc = fp_add<P>(acc, o);
+        }
+        __syncthreads();
+    }
+    return acc;
+}
+
+template <class P>
+__global__ __launch_bounds__(SPMV_LONG_THREADS) void spmv_items_kernel(const uint32_t* __restrict__ items /* (k0, k1) pairs */,
+                                                                       const uint32_t* __restrict__ cols, const uint32_t* __restrict__ vals,
+                                                                       const uint32_t* __restrict__ w, uint32_t* __restrict__ partials) {
+    __shared__ uint32_t sh[P::N * SPMV_LONG_THREADS];
+    const uint32_t k0 = items[2 * blockIdx.x], k1 = items[2 * blockIdx.x + 1];
+    Fp<P> acc = fp_zero<P>();
+    for (uint32_t k = k0 + threadIdx.x; k < k1; k += SPMV_LONG_THREADS) {
+        Fp<P> v = load_fr<P>(vals + (size_t)k * P::W);
+        Fp<P> x = load_fr<P>(w + (size_t)cols[k] * P::W);
+        acc = fp_add<P>(acc, fp_mul<P>(v, x));
+    }
+    acc = block_sum_fr<P>(acc, sh);
+    if (threadIdx.x == 0) store_fr<P>(partials + (size_t)blockIdx.x * P::W, acc);
+}
+
+template <class P>
+__global__ __launch_bounds__(SPMV_LONG_THREADS) void spmv_rows_kernel(const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ item_ptr,
+                                                                      const uint32_t* __restrict__ partials, uint32_t* __restrict__ out) {
+    __shared__ uint32_t sh[P::N * SPMV_LONG_THREADS];
+    const uint32_t i0 = item_ptr[blockIdx.x], i1 = item_ptr[blockIdx.x + 1];
+    Fp<P> acc = fp_zero<P>();
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += SPMV_LONG_THREADS) acc = fp_add<P>(acc, load_fr<P>(partials + (size_t)i * P::W));
+    acc = block_sum_fr<P>(acc, sh);
+    if (threadIdx.x == 0) store_fr<P>(out + (size_t)long_rows[blockIdx.x] * P::W, fp_reduce_full<P>(fp_mul<P>(acc, fp_const<P>(P::R2))));
 }
 
 // QAP tail: flag |= (lo[i] + hi[i] - w[i] != 0)
@@ -503,15 +560,34 @@ int zk_qap_h_dev(int curve, int log_n, void* d_a_u, void* d_b_v, const void* d_c
 }
 
 int zk_spmv_dev(int curve, uint64_t n_rows, const void* d_row_ptr, const void* d_cols, const void* d_vals,
-                const void* d_w, void* d_out, void* stream) {
+                const void* d_w, void* d_out, uint32_t skip_longer_than, void* stream) {
     if (n_rows == 0) return ZK_OK;
 #define CALL(P)                                                                                                  \
     {                                                                                                            \
         hipLaunchKernelGGL(spmv_kernel<P>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, \
                            n_rows, (const uint32_t*)d_row_ptr, (const uint32_t*)d_cols, (const uint32_t*)d_vals,  \
-                           (const uint32_t*)d_w, (uint32_t*)d_out);                                               \
+                           (const uint32_t*)d_w, (uint32_t*)d_out, skip_longer_than);                             \
         ZK_HIP(hipGetLastError());                                                                               \
         return ZK_OK;                                                                                            \
+    }
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_spmv_long_dev(int curve, uint64_t n_long, const void* d_long_rows, const void* d_item_ptr, uint64_t n_items,
+                     const void* d_items, const void* d_cols, const void* d_vals, const void* d_w, void* d_partials,
+                     void* d_out, void* stream) {
+    if (n_long == 0 || n_items == 0) return ZK_OK;
+#define CALL(P)                                                                                                          \
+    {                                                                                                                    \
+        hipLaunchKernelGGL(spmv_items_kernel<P>, dim3((unsigned)n_items), dim3(SPMV_LONG_THREADS), 0, (hipStream_t)stream, \
+                           (const uint32_t*)d_items, (const uint32_t*)d_cols, (const uint32_t*)d_vals,                   \
+                           (const uint32_t*)d_w, (uint32_t*)d_partials);                                                 \
+        hipLaunchKernelGGL(spmv_rows_kernel<P>, dim3((unsigned)n_long), dim3(SPMV_LONG_THREADS), 0, (hipStream_t)stream,   \
+                           (const uint32_t*)d_long_rows, (const uint32_t*)d_item_ptr, (const uint32_t*)d_partials,       \
+                           (uint32_t*)d_out);                                                                            \
+        ZK_HIP(hipGetLastError());                                                                                       \
+        return ZK_OK;                                                                                                    \
     }
     ZK_DISPATCH_FR(curve, CALL);
 #undef CALL

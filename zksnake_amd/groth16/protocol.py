@@ -23,6 +23,7 @@ from ..device import DeviceBuffer
 from ..ecc import EllipticCurve, PointArray
 from ..frvec import DevVec, FrOps
 from ..polynomial import POLY_OBJECT
+from ..spmv import DeviceCsr
 from ..utils import get_random_int
 from .qap import QAP
 from .serialization import Proof, ProvingKey, VerifyingKey
@@ -73,12 +74,10 @@ class Groth16:
         d_lag = V.d_from(mod.evaluate_lagrange_coefficients(n, tau, as_limbs=True))
         sums = []
         for mat in (self.qap.a, self.qap.b, self.qap.c):
-            col_ptr, rows, vals = mat.to_csc()
             out = DevVec(n_wires)
-            if len(rows):
-                bufs = [DeviceBuffer.from_numpy(x) for x in (col_ptr, rows, vals)]
-                N.check(lib.zk_spmv_dev(cid, n_wires, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, d_lag.ptr(), out.ptr(), None))
-                lib.zk_dev_synchronize()
+            csc = DeviceCsr(cid, *mat.to_csc())   # the transpose: one row per wire, the input wires' rows are long
+            csc.apply(d_lag.ptr(), out.ptr(), None)
+            lib.zk_dev_synchronize()
             sums.append(out)
         L, R, O = sums
         K = DevVec(n_wires, zero=False)

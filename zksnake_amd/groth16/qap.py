@@ -57,11 +57,8 @@ class QAP:
 
     def _device_matrices(self):
         if self._dev is None:
-            mats = []
-            for m in (self.a, self.b, self.c):
-                row_ptr, cols, vals = m.to_csr()
-                mats.append((DeviceBuffer.from_numpy(row_ptr), DeviceBuffer.from_numpy(cols), DeviceBuffer.from_numpy(vals)))
-            self._dev = mats
+            from ..spmv import DeviceCsr
+            self._dev = [DeviceCsr(self._curve_id(), *m.to_csr()) for m in (self.a, self.b, self.c)]
         return self._dev
 
     def _workspace(self, n, n_col):
@@ -116,8 +113,8 @@ class QAP:
             N.check(lib.zk_stream_synchronize(st))
         if after_upload is not None:
             after_upload(ws["w"])
-        for (rp, cl, vl), dst in zip(self._device_matrices(), (ws["a"], ws["b"], ws["c"])):
-            N.check(lib.zk_spmv_dev(cid, n, rp.ptr, cl.ptr, vl.ptr, ws["w"].ptr, dst.ptr, st))
+        for mat, dst in zip(self._device_matrices(), (ws["a"], ws["b"], ws["c"])):
+            mat.apply(ws["w"].ptr, dst.ptr, st)
         ok = N._i(0)
         N.check(lib.zk_qap_h_dev(cid, log_n, ws["a"].ptr, ws["b"].ptr, ws["c"].ptr, ws["h"].ptr, ws["work"].ptr, ok, st))
         if not ok.value:
