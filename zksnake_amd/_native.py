@@ -13,7 +13,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkmi.so")
+LIB_PATH = os.environ.get("ZKMI_LIB") or os.path.join(_HERE, "libzkmi.so")  # ZKMI_LIB: kernel-variant experiments
 
 ZK_OK = 0
 ZK_ERR_LENGTH = 1

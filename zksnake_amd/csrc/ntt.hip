@@ -13,6 +13,7 @@
 // tile (structure-of-arrays: limb-major, so consecutive lanes hit consecutive banks), then one
 // bit-reversal pass that also applies 1/N for the inverse transform.  Twiddles w^k (k < N/2)
 // are precomputed once per (field, size, direction) and streamed from HBM.
+#include <algorithm>
 #include <mutex>
 #include <map>
 #include <vector>
@@ -21,99 +22,124 @@
 
 namespace zkmi {
 
-constexpr int NTT_TILE_LOG = 10;  // 1024 elements = 32 KiB of LDS per workgroup
-constexpr int NTT_THREADS = 256;
-constexpr int NTT_Q = 3;          // 2^3 contiguous elements (256 B) per row of a strided tile
+constexpr int NTT_TILE_LOG = 11;   // 2048 elements = 72 KiB of LDS per workgroup (limb-major), two workgroups per CU
+#ifndef NTT_THREADS_N
+#define NTT_THREADS_N 512
+#endif
+#ifndef NTT_MIN_BLOCKS
+#define NTT_MIN_BLOCKS 2
+#endif
+constexpr int NTT_THREADS = NTT_THREADS_N;
+constexpr int NTT_MAX_DIGIT = 8;   // stages per pass: 2^8 x 2^3 runs of 256 B at least
 
 // ---- twiddle generation -------------------------------------------------------------------
-
+// Stage-major table, independent of the transform size: stage s of a DIF transform pairs (i, i + 2^s) and multiplies the
+// difference by zeta_{s+1}^(i mod 2^s), zeta_k = primitive 2^k-th root of unity.  Row s holds zeta_{s+1}^j, j < 2^s, at
+// offset 2^s - 1: consecutive butterflies read consecutive entries (the former single table w_n^k made every butterfly of
+// a low stage fetch its own 64-byte sector: one L2 request each).
 template <class P>
-__global__ void twiddle_kernel(uint32_t* out, Fp<P> w, uint32_t count) {
+__global__ void twiddle_kernel(uint32_t* out, Fp<P> zeta, uint32_t count) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= count) return;
     uint32_t e[1] = {k};
-    Fp<P> r = fp_pow<P>(w, e, 1);
+    Fp<P> r = fp_pow<P>(zeta, e, 1);
     store_fr<P>(out + (size_t)k * P::W, r);
 }
 
 // ---- butterfly passes -----------------------------------------------------------------------
-// One launch covers stages s_hi .. s_hi-m+1 of a DIF transform of size 2^log_n.  A workgroup owns
-// the 2^(m+q) elements  i = hi << (s_hi+1) | mid << s_lo | lo_blk << q | lo_in  (mid: m bits,
-// lo_in: q bits) and keeps them in LDS for all m stages.
-
-// `in` and `out` may be the same vector (every workgroup reads and writes the same index set) unless `final_pass` is
-// set: the last pass stores element i at the bit-reversed index (natural-order result), multiplied by `scale` when
-// use_scale != 0 (1/N of the inverse transform) and fully reduced -- so it must write to a different vector.
+// Decimation in frequency with the digit reversal folded into the passes.  Before a pass, `done` low bits of the
+// physical index hold finished (bit-reversed) frequency digits and the upper rem = log_n - done bits the remaining
+// logical index in natural order.  A pass takes the top m remaining bits D: a workgroup owns all 2^m values of D for a
+// run of 2^q consecutive values of the rest of the index (so every global access is a run of 2^q elements), performs
+// stages rem-1 .. rem-m on them in LDS and writes element (D, low, fin) to
+//        (low << (done + m)) | (bitrev_m(D) << done) | fin,
+// i.e. D's frequency digit lands just above the digits already finished.  After the last pass the vector is in natural
+// order: no scattered final store, no separate reordering pass.  `in` and `out` must be different vectors unless the
+// pass is the only one (a single workgroup that reads everything before it writes).
+// The last pass multiplies by `scale` when use_scale != 0 (1/N of the inverse transform) and stores canonical values;
+// the other passes keep values semi-reduced (< 2p).
 template <class P>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* in, uint32_t* out,
+__global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(const uint32_t* in, uint32_t* out,
                                                                const uint32_t* __restrict__ tw, int log_n,
-                                                               int s_hi, int m, int q, int final_pass, Fp<P> scale, int use_scale) {
+                                                               int rem, int m, int q, int final_pass, Fp<P> scale, int use_scale) {
     constexpr int N = P::N;  // register limbs (LDS is limb-major)
     constexpr int W = P::W;  // words per element in HBM
-    __shared__ uint32_t lds[N][1 << NTT_TILE_LOG];
+    extern __shared__ uint32_t lds[];  // [N][tile]
+    const int done = log_n - rem;
     const int tile_log = m + q;
-    const int tile = 1 << tile_log;
-    const int s_lo = s_hi - m + 1;
-    const uint32_t lo_blocks_log = s_lo - q;
-    const uint32_t t = blockIdx.x;
-    const uint32_t lo_blk = t & ((1u << lo_blocks_log) - 1);
-    const uint32_t hi = t >> lo_blocks_log;
-    const uint32_t base = (hi << (s_hi + 1)) | (lo_blk << q);
+    const uint32_t tile = 1u << tile_log;
+    const int rest_bits = log_n - m;
+    const uint32_t rest0 = blockIdx.x << q;
+    const uint32_t qmask = (1u << q) - 1;
+    // LDS element index, skewed by one bank per 2^(tile_log - 5) elements: the first pass reads its output along the
+    // bit-reversed digit (stride 2^q elements over the TOP five bits of the lane group), which would otherwise hit one bank
+    const int pad_shift = tile_log >= 10 ? tile_log - 5 : 31;
+    const uint32_t row = tile + 32;
+#define LIDX(e) ((e) + ((e) >> pad_shift))
 
-    for (int e = threadIdx.x; e < tile; e += NTT_THREADS) {
-        uint32_t mid = e >> q, lo_in = e & ((1u << q) - 1);
-        uint32_t idx = base | (mid << s_lo) | lo_in;
-        Fp<P> x = load_fr<P>(in + (size_t)idx * W);
+    for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
+        const uint32_t d = e >> q, r = e & qmask;
+        const uint32_t p = (d << rest_bits) | rest0 | r;
+        Fp<P> x = load_fr<P>(in + (size_t)p * W);
+        const uint32_t le = LIDX(e);
 #pragma unroll
-        for (int l = 0; l < N; ++l) lds[l][e] = x.v[l];
+        for (int l = 0; l < N; ++l) lds[l * row + le] = x.v[l];
     }
     __syncthreads();
 
     for (int b = m - 1; b >= 0; --b) {
-        const int s = s_lo + b;
+        const int s = rem - m + b;
         const int pos = b + q;
-        for (int u = threadIdx.x; u < (tile >> 1); u += NTT_THREADS) {
-            uint32_t e0 = ((u >> pos) << (pos + 1)) | (u & ((1u << pos) - 1));
-            uint32_t e1 = e0 | (1u << pos);
-            uint32_t mid0 = e0 >> q, lo_in = e0 & ((1u << q) - 1);
-            uint32_t i0 = base | (mid0 << s_lo) | lo_in;
-            uint32_t k = (i0 & ((1u << s) - 1)) << (log_n - 1 - s);
+        const uint32_t* tws = tw + ((size_t)(1u << s) - 1) * W;
+        for (uint32_t u = threadIdx.x; u < (tile >> 1); u += NTT_THREADS) {
+            const uint32_t e0 = ((u >> pos) << (pos + 1)) | (u & ((1u << pos) - 1));
+            const uint32_t e1 = e0 | (1u << pos);
+            const uint32_t d0 = e0 >> q, r = e0 & qmask;
+            const uint32_t low = (rest0 | r) >> done;                              // remaining logical bits below D
+            const uint32_t j = ((d0 & ((1u << b) - 1)) << (rem - m)) | low;        // i mod 2^s
             Fp<P> x, y;
+            const uint32_t l0 = LIDX(e0), l1 = LIDX(e1);
 #pragma unroll
-            for (int l = 0; l < N; ++l) { x.v[l] = lds[l][e0]; y.v[l] = lds[l][e1]; }
-            Fp<P> w = load_fr<P>(tw + (size_t)k * W);
+            for (int l = 0; l < N; ++l) { x.v[l] = lds[l * row + l0]; y.v[l] = lds[l * row + l1]; }
+            Fp<P> w = load_fr<P>(tws + (size_t)j * W);
             Fp<P> sum = fp_add<P>(x, y);
-            Fp<P> dif = fp_mul<P>(w, fp_sub_lazy<P>(x, y));  // (x - y + 2p) un-normalized: fine as a product operand
+            Fp<P> dif = fp_mul<P>(w, fp_sub_lazy<P>(x, y));  // (x - y + 4p) un-normalized: fine as a product operand
 #pragma unroll
-            for (int l = 0; l < N; ++l) { lds[l][e0] = sum.v[l]; lds[l][e1] = dif.v[l]; }
+            for (int l = 0; l < N; ++l) { lds[l * row + l0] = sum.v[l]; lds[l * row + l1] = dif.v[l]; }
         }
         __syncthreads();
     }
 
-    for (int e = threadIdx.x; e < tile; e += NTT_THREADS) {
-        uint32_t mid = e >> q, lo_in = e & ((1u << q) - 1);
-        uint32_t idx = base | (mid << s_lo) | lo_in;
+    const uint32_t fin_mask = done >= 32 ? 0xFFFFFFFFu : ((1u << done) - 1);
+    for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
+        // walk the OUTPUT in its run order: with done >= q the run (low q bits) stays in place and D' is next
+        uint32_t d, r;
+        if (done >= q) { r = e & qmask; d = e >> q; }
+        else { d = e & ((1u << m) - 1); r = e >> m; }      // first pass: D' is the fastest output digit
+        const uint32_t src = (__brev(d) >> (32 - m)) << q | r;  // element whose D equals bitrev(d)
+        const uint32_t rest = rest0 | r;
+        const uint32_t po = ((rest >> done) << (done + m)) | (d << done) | (rest & fin_mask);
         Fp<P> x;
+        const uint32_t ls = LIDX(src);
 #pragma unroll
-        for (int l = 0; l < N; ++l) x.v[l] = lds[l][e];
+        for (int l = 0; l < N; ++l) x.v[l] = lds[l * row + ls];
         if (final_pass) {
-            // the passes keep values semi-reduced (< 2p): the result is stored canonical, in natural order
             if (use_scale) x = fp_mul<P>(x, scale);
-            idx = __brev(idx) >> (32 - log_n);
             x = fp_reduce_full<P>(x);
         }
-        store_fr<P>(out + (size_t)idx * W, x);
+        store_fr<P>(out + (size_t)po * W, x);
     }
+#undef LIDX
 }
 
-// x[i] *= g^(+-i) with g = w (table holds w^k for k < n/2; w^(n/2) = -1)
+// x[i] *= g^(+-i) with g = w_n: row log_n - 1 of the stage-major table holds w_n^k for k < n/2; w_n^(n/2) = -1
 template <class P>
 __global__ void coset_scale_kernel(uint32_t* data, const uint32_t* tw, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (n == 1) return;
     uint32_t half = n >> 1;
-    Fp<P> w = load_fr<P>(tw + (size_t)(i & (half - 1)) * P::W);
+    Fp<P> w = load_fr<P>(tw + ((size_t)(half - 1) + (i & (half - 1))) * P::W);
     if (i >= half) w = fp_neg<P>(w);
     Fp<P> a = load_fr<P>(data + (size_t)i * P::W);
     store_fr<P>(data + (size_t)i * P::W, fp_reduce_full<P>(fp_mul<P>(a, w)));
@@ -263,34 +289,42 @@ __global__ void qap_check_kernel(uint64_t n, const uint32_t* lo, const uint32_t*
 struct TwiddleSet {
     uint32_t* fwd = nullptr;
     uint32_t* inv = nullptr;
+    int stages = 0;  // rows 0 .. stages-1 are built (enough for transforms up to 2^stages)
 };
 
 static std::mutex g_tw_mutex;
-static std::map<std::pair<int, int>, TwiddleSet> g_twiddles;  // (curve, log_n)
+static std::map<int, TwiddleSet> g_twiddles;          // per curve
+static std::vector<void*> g_tw_retired;               // smaller tables replaced by a bigger one: other streams may still read them
 
 template <class P>
-static Fp<P> host_root(int log_n, bool inverse) {
+static Fp<P> host_root(int log_order, bool inverse) {
+    // primitive 2^log_order-th root of unity (or its inverse)
     Fp<P> w = fp_const<P>(inverse ? P::ROOT_INV : P::ROOT);
-    for (int k = 0; k < P::TWO_ADICITY - log_n; ++k) w = fp_sqr<P>(w);
+    for (int k = 0; k < P::TWO_ADICITY - log_order; ++k) w = fp_sqr<P>(w);
     return w;
 }
 
 template <class P>
 static int get_twiddles(int curve, int log_n, TwiddleSet* out, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_tw_mutex);
-    auto key = std::make_pair(curve, log_n);
-    auto it = g_twiddles.find(key);
-    if (it != g_twiddles.end()) { *out = it->second; return ZK_OK; }
+    TwiddleSet& cur = g_twiddles[curve];
+    if (cur.stages >= log_n) { *out = cur; return ZK_OK; }
     TwiddleSet ts;
-    uint32_t count = log_n == 0 ? 1 : (1u << (log_n - 1));
-    size_t bytes = (size_t)count * P::W * 4;
+    ts.stages = log_n < 16 ? 16 : log_n;  // small transforms share one 2 MiB table
+    if (ts.stages > P::TWO_ADICITY) ts.stages = P::TWO_ADICITY;
+    const size_t bytes = (((size_t)1 << ts.stages) - 1) * P::W * 4;
     ZK_HIP(hipMalloc(&ts.fwd, bytes));
     ZK_HIP(hipMalloc(&ts.inv, bytes));
-    hipLaunchKernelGGL(twiddle_kernel<P>, dim3((count + 255) / 256), dim3(256), 0, stream, ts.fwd, host_root<P>(log_n, false), count);
-    hipLaunchKernelGGL(twiddle_kernel<P>, dim3((count + 255) / 256), dim3(256), 0, stream, ts.inv, host_root<P>(log_n, true), count);
+    for (int s = 0; s < ts.stages; ++s) {
+        const uint32_t count = 1u << s;
+        const size_t off = ((size_t)count - 1) * P::W;
+        hipLaunchKernelGGL(twiddle_kernel<P>, dim3((count + 255) / 256), dim3(256), 0, stream, ts.fwd + off, host_root<P>(s + 1, false), count);
+        hipLaunchKernelGGL(twiddle_kernel<P>, dim3((count + 255) / 256), dim3(256), 0, stream, ts.inv + off, host_root<P>(s + 1, true), count);
+    }
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipStreamSynchronize(stream));
-    g_twiddles[key] = ts;
+    if (cur.fwd) { g_tw_retired.push_back(cur.fwd); g_tw_retired.push_back(cur.inv); }
+    cur = ts;
     *out = ts;
     return ZK_OK;
 }
@@ -303,9 +337,11 @@ static void free_twiddles() {
         (void)hipFree(kv.second.inv);
     }
     g_twiddles.clear();
+    for (void* p : g_tw_retired) (void)hipFree(p);
+    g_tw_retired.clear();
 }
 
-// Scratch vector of the transform, one per stream (work on a stream is ordered, so reuse is safe); grow-only.
+// Scratch vectors of the transform, one set per stream (work on a stream is ordered, so reuse is safe); grow-only.
 struct NttScratch {
     uint32_t* ptr = nullptr;
     size_t bytes = 0;
@@ -336,51 +372,54 @@ static void free_scratch() {
     g_scratch.clear();
 }
 
-// Pass plan: the low min(log_n, 10) stages form the last, contiguous pass (1024 consecutive elements per workgroup);
-// the stages above are split evenly over ceil(R / 7) strided passes of m stages on 2^m rows x 2^(10-m) contiguous
-// elements -- an even split keeps the contiguous runs as long as possible (2^22: 6 + 6 + 10 with 512-byte runs).
-// Data flow: first pass d -> scratch, middle passes in place on scratch, last pass scratch -> d at bit-reversed
-// indices (+ 1/N, + canonical reduction), so no separate reordering pass.  A transform without strided stages
-// (log_n <= 10) first copies d to the scratch vector, because the permuting pass cannot run in place.
+// Pass plan: ceil(log_n / 8) passes, the stages split as evenly as possible with the larger digits LAST (the later
+// passes share one twiddle among the 2^q elements of a run and read small table rows; the first pass streams one twiddle
+// per butterfly).  2^22 = 7 + 7 + 8 stages on tiles of 128 x 16, 128 x 16 and 256 x 8 elements: every global access is a
+// run of 256 or 512 bytes.  Data flow: d -> scratch A -> scratch B -> ... -> d (a single pass runs in place: one
+// workgroup holds the whole vector).
 template <class P>
 static int ntt_dev_impl(int curve, int inverse, int log_n, uint32_t* d, hipStream_t stream) {
     if (log_n < 0 || log_n > P::TWO_ADICITY || log_n > 30) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
     if (log_n == 0) return ZK_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ZK_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(P::N * ((1u << NTT_TILE_LOG) + 32) * 4)));
+        attr_set = true;
+    }
     TwiddleSet ts;
     int rc = get_twiddles<P>(curve, log_n, &ts, stream);
     if (rc) return rc;
     const uint32_t* tw = inverse ? ts.inv : ts.fwd;
     const size_t bytes = ((size_t)1 << log_n) * P::W * 4;
-    uint32_t* scratch = nullptr;
-    if ((rc = get_scratch(stream, bytes, &scratch))) return rc;
     Fp<P> scale = fp_one<P>();
     if (inverse) {
         uint32_t nn[P::W] = {0};
         nn[0] = 1u << log_n;
         scale = fp_inv<P>(fp_from_canonical<P>(nn));
     }
-    const int last = log_n < NTT_TILE_LOG ? log_n : NTT_TILE_LOG;  // stages of the contiguous pass
-    const int upper = log_n - last;                                 // stages of the strided passes
-    const int max_m = NTT_TILE_LOG - NTT_Q;
-    const int n_strided = (upper + max_m - 1) / max_m;
+    const int passes = log_n <= NTT_TILE_LOG ? 1 : (log_n + NTT_MAX_DIGIT - 1) / NTT_MAX_DIGIT;
+    uint32_t* scratch = nullptr;
+    if (passes > 1 && (rc = get_scratch(stream, bytes * (passes > 2 ? 2 : 1), &scratch))) return rc;
+    uint32_t* bufs[2] = {scratch, scratch ? scratch + (bytes / 4) : nullptr};
     const uint32_t* src = d;
-    int s = log_n - 1;
-    for (int i = 0; i < n_strided; ++i) {
-        const int m = upper / n_strided + (i < upper % n_strided ? 1 : 0);
-        const int s_lo = s - m + 1;
-        const int q = s_lo < NTT_TILE_LOG - m ? s_lo : NTT_TILE_LOG - m;
-        const uint32_t tiles = 1u << (log_n - m - q);
-        hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(tiles), dim3(NTT_THREADS), 0, stream, src, scratch, tw, log_n, s, m, q, 0, scale, 0);
-        src = scratch;
-        s -= m;
+    int rem = log_n, which = 0;
+    for (int i = 0; i < passes; ++i) {
+        // digits: the first (log_n mod passes complement) passes get floor, the last ones ceil
+        const int left = passes - i;
+        const int m = passes == 1 ? log_n : rem / left;   // floor now, the remainder accumulates towards the last passes
+        const int rest_bits = log_n - m;
+        const int q = passes == 1 ? 0 : std::min(NTT_TILE_LOG - m, rest_bits);
+        const bool last = i == passes - 1;
+        uint32_t* dst = last ? d : bufs[which];
+        const uint32_t tile = 1u << (m + q);
+        const size_t lds_bytes = (size_t)P::N * (tile + 32) * 4;
+        hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(1u << (rest_bits - q)), dim3(NTT_THREADS), lds_bytes, stream, src, dst, tw, log_n, rem, m, q,
+                           last ? 1 : 0, scale, (last && inverse) ? 1 : 0);
+        src = dst;
+        which ^= 1;
+        rem -= m;
     }
-    if (n_strided == 0) {
-        // no strided pass put the data into the scratch vector: the final pass may not run in place, so stage a copy
-        ZK_HIP(hipMemcpyAsync(scratch, d, bytes, hipMemcpyDeviceToDevice, stream));
-        src = scratch;
-    }
-    hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(1u << (log_n - last)), dim3(NTT_THREADS), 0, stream, src, d, tw, log_n, last - 1, last, 0, 1,
-                       scale, inverse ? 1 : 0);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
