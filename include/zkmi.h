@@ -145,6 +145,9 @@ int zk_msm_plan_create(int curve, int group, uint64_t n, const void* bases, int 
  * n = 1 plan (or compute ceil((bits + 1) / c)) to learn the window count first. */
 int zk_msm_plan_create_range(int curve, int group, uint64_t n, const void* bases, int bases_on_device, int flags,
                              int window_bits, int window_first, int window_count, uint64_t* handle);
+/* A second plan over the SAME device-resident bases (and fixed-base table; shared, freed with the last user) with its
+ * own workspace and stream, so that two MSMs against one key can be in flight together. */
+int zk_msm_plan_clone(uint64_t handle, uint64_t* clone_handle);
 int zk_msm_plan_destroy(uint64_t handle);
 /* scalars: n_scalars <= plan n canonical Fr elements (host or device per `scalars_on_device`); the
  * first n_scalars bases are used (ecc.py:118-119 truncation rule).  Result: one affine point in host

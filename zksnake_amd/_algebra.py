@@ -57,6 +57,7 @@ class PointArray:
         self.group = group
         self.limbs = np.ascontiguousarray(limbs, dtype=np.uint64).reshape(-1, N.point_limbs(curve_id, group))
         self._plans = {}
+        self.window_range = None  # (first, count): plans cover only these windows (a rank of a window-sharded prover)
 
     def __len__(self):
         return self.limbs.shape[0]
@@ -83,8 +84,18 @@ class PointArray:
         if key not in self._plans:
             lib = N.ensure_gpu()
             h = N._u64(0)
-            flags = (N.MSM_PRECOMPUTE if precompute else 0) | (N.MSM_HIGH_PRIORITY if high_priority else 0)
-            N.check(lib.zk_msm_plan_create(self.curve_id, self.group, len(self), self.limbs.ctypes.data, 0, flags, 0, h))
+            other = next((v for (s, p), v in self._plans.items() if p == bool(precompute)), None)
+            if other is not None:
+                # further slots share the first plan's bases (and its fixed-base table): only the workspace is new
+                N.check(lib.zk_msm_plan_clone(other, h))
+            else:
+                flags = (N.MSM_PRECOMPUTE if precompute else 0) | (N.MSM_HIGH_PRIORITY if high_priority else 0)
+                if self.window_range is not None:
+                    first, count = self.window_range
+                    N.check(lib.zk_msm_plan_create_range(self.curve_id, self.group, len(self), self.limbs.ctypes.data, 0, flags, 0,
+                                                         first, count, h))
+                else:
+                    N.check(lib.zk_msm_plan_create(self.curve_id, self.group, len(self), self.limbs.ctypes.data, 0, flags, 0, h))
             self._plans[key] = h.value
         return self._plans[key]
 

@@ -69,6 +69,7 @@ SIGNATURES = {
     "zk_batch_mul": (_i, [_i, _i, _u64, _u64p, _u64p, _i, _u64p]),
     "zk_msm_plan_create": (_i, [_i, _i, _u64, _vp, _i, _i, _i, _u64p]),
     "zk_msm_plan_create_range": (_i, [_i, _i, _u64, _vp, _i, _i, _i, _i, _i, _u64p]),
+    "zk_msm_plan_clone": (_i, [_u64, _u64p]),
     "zk_msm_plan_destroy": (_i, [_u64]),
     "zk_msm_plan_run": (_i, [_u64, _u64, _vp, _i, _i, _i, _u64p, _vp]),
     "zk_msm_plan_enqueue": (_i, [_u64, _u64, _vp, _i, _i, _i, _vp]),

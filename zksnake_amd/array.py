@@ -12,6 +12,18 @@ import numpy as np
 from . import _native as N
 
 
+def _stable_order(keys):
+    """argsort(keys, kind="stable") for non-negative integer keys below 2^32 and fewer than 2^32 entries: the
+    position rides in the low half of a 64-bit sort key, so numpy's (vectorised, unstable) integer sort can be used --
+    several times faster than its stable merge sort on 2^20 and more entries"""
+    n = keys.shape[0]
+    if n == 0 or n >= (1 << 32) or int(keys.max()) >= (1 << 32):
+        return np.argsort(keys, kind="stable")
+    packed = (keys.astype(np.uint64) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    packed.sort()
+    return (packed & np.uint64(0xFFFFFFFF)).astype(np.int64)
+
+
 class SparseArray:
     def __init__(self, matrix, n_row, n_col, p):
         self.p = p
@@ -90,11 +102,15 @@ class SparseArray:
                 raise IndexError(f"row index out of range for a matrix with {self.n_row} rows")
             if cols.size and (int(cols.min()) < 0 or int(cols.max()) >= self.n_col):
                 raise IndexError(f"column index out of range for a matrix with {self.n_col} columns")
-            order = np.argsort(rows, kind="stable")
             counts = np.bincount(rows, minlength=self.n_row)
             row_ptr = np.zeros(self.n_row + 1, dtype=np.uint32)
             np.cumsum(counts, out=row_ptr[1:])
-            self._csr = (row_ptr, cols[order].astype(np.uint32), np.ascontiguousarray(vals[order]))
+            if rows.size < 2 or bool((rows[1:] >= rows[:-1]).all()):
+                # triplets already in row order (how circuits are usually emitted): nothing to permute
+                self._csr = (row_ptr, cols.astype(np.uint32), np.ascontiguousarray(vals))
+            else:
+                order = _stable_order(rows)
+                self._csr = (row_ptr, cols[order].astype(np.uint32), np.ascontiguousarray(vals[order]))
         return self._csr
 
     def _value_limbs(self, vals):
@@ -128,7 +144,7 @@ class SparseArray:
         if self._csc is None or self._csr is None:
             row_ptr, cols, vals = self.to_csr()
             rows = np.repeat(np.arange(self.n_row, dtype=np.uint32), np.diff(row_ptr.astype(np.int64)))
-            order = np.argsort(cols, kind="stable")
+            order = _stable_order(cols.astype(np.int64))
             col_ptr = np.zeros(self.n_col + 1, dtype=np.uint32)
             np.cumsum(np.bincount(cols, minlength=self.n_col), out=col_ptr[1:])
             self._csc = (col_ptr, np.ascontiguousarray(rows[order]), np.ascontiguousarray(vals[order]))

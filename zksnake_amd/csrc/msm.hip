@@ -46,6 +46,23 @@ int zk_msm_plan_create_range(int curve, int group, uint64_t n, const void* bases
     return ZK_OK;
 }
 
+int zk_msm_plan_clone(uint64_t handle, uint64_t* clone_handle) {
+    MsmPlanBase* src = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_plan_mutex);
+        auto it = g_plans.find(handle);
+        if (it == g_plans.end()) return fail(ZK_ERR_ARG, "unknown MSM plan handle");
+        src = it->second;
+    }
+    MsmPlanBase* p = nullptr;
+    int rc = src->clone(&p);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    *clone_handle = g_next_plan++;
+    g_plans[*clone_handle] = p;
+    return ZK_OK;
+}
+
 int zk_msm_plan_destroy(uint64_t handle) {
     MsmPlanBase* p = nullptr;
     {

@@ -25,6 +25,7 @@
 //                  field multiplication, the host ~50 ns.
 #pragma once
 #include <algorithm>
+#include <memory>
 #include <vector>
 #include "common.cuh"
 #include "msm_plan.h"
@@ -1090,6 +1091,7 @@ struct MsmPlan : MsmPlanBase {
     int range_log = 0;  // general mode: log2(buckets per sort workgroup)
     Work ws;
     // shared device buffers
+    std::shared_ptr<DeviceBlock> bases_block;  // the (table of) bases: shared by the clones of a plan
     uint32_t* d_bases = nullptr;
     uint32_t* d_scalars = nullptr;
     uint16_t* d_dig = nullptr;
@@ -1099,7 +1101,7 @@ struct MsmPlan : MsmPlanBase {
     ~MsmPlan() override {
         void* bufs[] = {ws.hist, ws.total, ws.bstart, ws.sstart, ws.bsums, ws.grand, ws.big_list, ws.big_count,
                         ws.sorted, ws.partials, ws.buckets, ws.rows, ws.fin, ws.tmp_ref, ws.bin_start,
-                        d_bases, d_scalars, d_dig};
+                        d_scalars, d_dig};
         for (void* q : bufs) if (q) (void)hipFree(q);
         if (h_final) (void)hipHostFree(h_final);
         for (hipEvent_t e : {ws.ev_begin, ws.ev_acc0, ws.ev_acc1, ws.ev_done, ev_start, ev_digits, ev_end}) if (e) (void)hipEventDestroy(e);
@@ -1108,7 +1110,10 @@ struct MsmPlan : MsmPlanBase {
 
     // Every allocation lands in a member that the destructor frees, and the factory deletes the plan when init() fails
     // (msm_group.hip), so a failing hipMalloc half way through leaks nothing.
-    int init(uint64_t n_points, const void* bases, int bases_on_device, int flags, int window_bits, int win_first, int win_count) {
+    // `share` != nullptr: a clone -- same bases (and fixed-base table), own workspace and stream
+    int init(uint64_t n_points, const void* bases, int bases_on_device, int flags, int window_bits, int win_first, int win_count,
+             const MsmPlan* share = nullptr) {
+        create_flags = flags;
         pre = (flags & ZK_MSM_PRECOMPUTE) != 0;
         if (n_points == 0 || n_points > (1ull << 26)) return fail(ZK_ERR_ARG, "MSM size must be in [1, 2^26]");
         n = n_points;
@@ -1145,26 +1150,33 @@ struct MsmPlan : MsmPlanBase {
             ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
             ZK_HIP(hipStreamCreateWithPriority(&own_stream, hipStreamDefault, (flags & ZK_MSM_HIGH_PRIORITY) ? hi : lo));
         }
-        ZK_HIP(hipMalloc(&d_bases, (pre ? (uint64_t)pw_count : 1ull) * n * AW * 4));
-        if (bases_on_device) {
-            hipLaunchKernelGGL(bases_to_mont_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0,
-                               (const uint32_t*)bases, n, d_bases);
+        if (share) {
+            bases_block = share->bases_block;
+            d_bases = share->d_bases;
         } else {
-            uint32_t* tmp = nullptr;
-            ZK_HIP(hipMalloc(&tmp, n * AW * 4));
-            hipError_t e = hipMemcpy(tmp, bases, n * AW * 4, hipMemcpyHostToDevice);
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(bases_to_mont_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, tmp, n, d_bases);
-                e = hipDeviceSynchronize();
+            bases_block = std::make_shared<DeviceBlock>();
+            ZK_HIP(hipMalloc(&bases_block->ptr, (pre ? (uint64_t)pw_count : 1ull) * n * AW * 4));
+            d_bases = (uint32_t*)bases_block->ptr;
+            if (bases_on_device) {
+                hipLaunchKernelGGL(bases_to_mont_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0,
+                                   (const uint32_t*)bases, n, d_bases);
+            } else {
+                uint32_t* tmp = nullptr;
+                ZK_HIP(hipMalloc(&tmp, n * AW * 4));
+                hipError_t e = hipMemcpy(tmp, bases, n * AW * 4, hipMemcpyHostToDevice);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(bases_to_mont_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, tmp, n, d_bases);
+                    e = hipDeviceSynchronize();
+                }
+                (void)hipFree(tmp);
+                ZK_HIP(e);
             }
-            (void)hipFree(tmp);
-            ZK_HIP(e);
-        }
-        ZK_HIP(hipGetLastError());
-        if (pre) {
-            // rows 2^(c w) P_i for the windows of this plan only (a sharded rank never builds the other ranks' rows)
-            int rc = precompute_table<G>(d_bases, n, c, pw_first, pw_count);
-            if (rc) return rc;
+            ZK_HIP(hipGetLastError());
+            if (pre) {
+                // rows 2^(c w) P_i for the windows of this plan only (a sharded rank never builds the other ranks' rows)
+                int rc = precompute_table<G>(d_bases, n, c, pw_first, pw_count);
+                if (rc) return rc;
+            }
         }
         ZK_HIP(hipMalloc(&d_scalars, n * FrP::W * 4));
         ZK_HIP(hipMalloc(&d_dig, (size_t)pw_count * (n + 8) * 2));
@@ -1343,6 +1355,18 @@ struct MsmPlan : MsmPlanBase {
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipMemcpyAsync(h_final, l.fin, (size_t)groups * (bpr + bpc) * 2 * XW * 4, hipMemcpyDeviceToHost, st));
         ZK_HIP(hipEventRecord(l.ev_done, st));
+        return ZK_OK;
+    }
+
+    int create_flags = 0;
+    int clone(MsmPlanBase** out) override {
+        MsmPlan* p = new MsmPlan();
+        int rc = p->init(n, nullptr, 0, create_flags & ~ZK_MSM_HIGH_PRIORITY, c, pw_first, pw_count, this);
+        if (rc) {
+            delete p;
+            return rc;
+        }
+        *out = p;
         return ZK_OK;
     }
 

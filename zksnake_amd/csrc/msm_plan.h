@@ -7,8 +7,19 @@
 
 namespace zkmi {
 
+// a device allocation with shared ownership (the bases / fixed-base table of a plan and its clones)
+struct DeviceBlock {
+    void* ptr = nullptr;
+    ~DeviceBlock() {
+        if (ptr) (void)hipFree(ptr);
+    }
+};
+
 struct MsmPlanBase {
     virtual ~MsmPlanBase() {}
+    // a second plan over the same bases (shared, read-only) with its own workspace and stream: two MSMs against one key
+    // in flight together (tau_1 with u and with v in Groth16.prove) without building the fixed-base table twice
+    virtual int clone(MsmPlanBase** out) = 0;
     // enqueue() puts every GPU stage plus the D2H copy of the per-window results on `stream` and returns;
     // finish() waits for them and runs the host tail.  run() = enqueue() + finish().
     virtual int enqueue(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count,

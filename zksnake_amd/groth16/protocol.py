@@ -71,7 +71,13 @@ class Groth16:
         lib, cid = N.ensure_gpu(), self.E.curve.curve_id
         # Lagrange basis at tau (host C++, one inversion), then everything per-wire on the GPU:
         # L = A^T lag, R = B^T lag, O = C^T lag (transposed CSR SpMV), K = beta L + alpha R + O
-        d_lag = V.d_from(mod.evaluate_lagrange_coefficients(n, tau, as_limbs=True))
+        # L_i(tau) = (1/n) sum_j tau^j w^(-ij): the inverse transform of the powers of tau (one 0.2 ms iNTT instead of
+        # n sequential host products and an inversion, evaluate_lagrange_coefficients of polynomial.rs:645-652)
+        powers = V.powers(tau, n)
+        d_pow = V.d_from(powers)
+        d_lag = DevVec(n, zero=False)
+        V.d_copy(n, d_pow.ptr(), d_lag.ptr())
+        V.d_ntt(d_lag, n, inverse=True)
         sums = []
         for mat in (self.qap.a, self.qap.b, self.qap.c):
             out = DevVec(n_wires)
@@ -91,8 +97,6 @@ class Groth16:
 
         # powers of tau and their t(tau)/delta multiples
         t = mod.evaluate_vanishing_polynomial(n, tau)
-        powers = V.powers(tau, n)
-        d_pow = V.d_from(powers)
         N.check(lib.zk_vec_axpby_dev(cid, n, N.u64p(V.one(t * inv_delta % q)), d_pow.ptr(), None, None, None, d_pow.ptr(), None))
         shifted = d_pow.download()
 
