@@ -164,6 +164,35 @@ def test_groth16_bls12_381_chain_2_10(gpu):
     assert len(proof.to_bytes()) == 192 and g.verify(proof, w[:2])
 
 
+@pytest.mark.parametrize("curve,log_n", [("BN254", 20), ("BLS12_381", 20), ("BLS12_381", 22)])
+def test_full_size_proof_equals_committed_closed_form(gpu, curve, log_n):
+    """BASELINE config 4 (BN254, 2^20 constraints) and the config-5 circuit (BLS12-381) at 2^20 and 2^22: the proof bytes of
+    the benchmark chain circuit equal the closed-form proof computed as discrete logarithms by the definitional oracle
+    (tests/golden/groth16_vectors.json, gen_groth16_golden.py: no FFT, no MSM).  Limb-array witnesses and, at 2^20 BN254, the
+    reference API's list[int] witnesses; the proof also passes the product's pairing verifier."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "groth16_vectors.json")) as f:
+        gold = json.load(f)[curve][str(log_n)]
+    cv = pyref.curve_by_name(curve)
+    n = 1 << log_n
+    A, B, C, w, n_col = W.chain_circuit(n, cv.r)
+    g = Groth16(R1CS.from_triplets(A, B, C, n, n_col, 2, curve), curve)
+    g._toxic = tuple(W.field_stream(W.SEED_PROVE, 5, cv.r)[1])
+    g._blinding = tuple(W.field_stream(W.SEED_PROVE, 2, cv.r, offset=5)[1])
+    g.setup()
+    proof = g.prove(N.ints_to_limbs(w[:2]), N.ints_to_limbs(w[2:]))
+    assert proof.to_bytes().hex() == gold["proof_hex"]
+    assert g.verify(proof, w[:2])
+    if (curve, log_n) == ("BN254", 20):
+        assert g.prove(w[:2], w[2:]).to_bytes().hex() == gold["proof_hex"]      # reference call shape: lists of ints
+        bad = list(w)
+        bad[5] = (bad[5] + 1) % cv.r
+        with pytest.raises(ValueError, match="Failed to evaluate"):
+            g.prove(bad[:2], N.ints_to_limbs(bad[2:]))
+        assert g.prove(N.ints_to_limbs(w[:2]), N.ints_to_limbs(w[2:])).to_bytes().hex() == gold["proof_hex"]  # and recovers
+
+
 def test_groth16_from_circom(gpu):
     """the reference's test_groth16_from_circom (tests/test_groth16.py:92-115) in the same shape: load the circom
     fixture with its symbol file, solve from the named inputs, compile, generate the witness, setup, prove, verify"""

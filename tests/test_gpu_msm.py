@@ -248,6 +248,51 @@ def test_msm_closed_form_other_groups(gpu, cid, grp, log_n):
     _known_dl_case(gpu, n, sc_limbs, sc_ints, cid, grp)
 
 
+def _bases_from_library(gpu, cid, grp, n, seed):
+    """n points k_i G made by zk_batch_mul (fast); they are only INPUTS here -- the expectation comes from the CPU oracle"""
+    r = (pyref.BN254 if cid == 0 else pyref.BLS12_381).r
+    ks = W.splitmix64(seed, 4 * n).reshape(n, 4)
+    ks[:, 3] &= np.uint64((1 << 60) - 1)
+    gen = generator_limbs(gpu, cid, grp)
+    bases = np.zeros((n, N.point_limbs(cid, grp)), dtype=np.uint64)
+    N.check(gpu.zk_batch_mul(cid, grp, n, N.u64p(ks), N.u64p(gen), 1, N.u64p(bases)))
+    assert (bases[:64] == corc.batch_mul(cid, grp, ks[:64], gen)).all()       # spot check of the inputs themselves
+    return bases, r
+
+
+@pytest.mark.parametrize("cid,grp,log_n", [(0, 1, 20), (0, 2, 19), (1, 1, 19), (1, 2, 19)])
+def test_msm_full_size_against_cpu_oracle(gpu, cid, grp, log_n):
+    """BASELINE config 2 (BN254 G1, 2^20 pairs) and the other three groups at 2^19, compared DIRECTLY with the CPU
+    restatement of ark's Pippenger (oracle/zk_oracle.cpp, all host cores) -- not through the library's own
+    batch_mul / point_mul closed form.  Both plan modes: the general path (two-level sort at n >= 2^19) and the fixed-base
+    table with its shared bucket set (ZK_MSM_PRECOMPUTE, what every 2^20 proof runs), plus a window-range split of each."""
+    import os
+    from zksnake_amd.parallel import sum_points, window_ranges
+    n = 1 << log_n
+    bases, r = _bases_from_library(gpu, cid, grp, n, 0xB45E5 + 16 * cid + grp)
+    sc = W.field_stream(W.SEED_MSM_SCALARS + 7 * cid + grp, n, r)[0]
+    sc[:3] = N.ints_to_limbs([0, 1, r - 1])
+    exp = corc.msm(cid, grp, sc, bases, threads=min(16, os.cpu_count() or 1))
+    PW = N.point_limbs(cid, grp)
+    for flags in (0, N.MSM_PRECOMPUTE):
+        h = N._u64(0)
+        N.check(gpu.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, flags, 0, h))
+        try:
+            out = np.zeros(PW, dtype=np.uint64)
+            N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, 0, 0, N.u64p(out), None))
+            assert (out == exp).all(), f"flags={flags}"
+            cb, nw = N._i(0), N._i(0)
+            N.check(gpu.zk_msm_plan_windows(h, cb, nw))
+            parts = []
+            for first, count in window_ranges(nw.value, 8):                  # the 8-rank split of BASELINE config 5
+                part = np.zeros(PW, dtype=np.uint64)
+                N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, first, count, N.u64p(part), None))
+                parts.append(part)
+            assert (sum_points(cid, grp, parts) == exp).all(), f"flags={flags} sharded"
+        finally:
+            N.check(gpu.zk_msm_plan_destroy(h))
+
+
 def test_msm_skewed_scalars(gpu):
     """benchmark-witness-like single-bit scalars and one hot bucket (SURVEY 8d skew variant)"""
     n = 1 << 16
