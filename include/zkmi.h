@@ -166,6 +166,9 @@ int zk_msm_plan_enqueue(uint64_t handle, uint64_t n_scalars, const void* scalars
                         int window_first, int window_count, void* stream);
 int zk_msm_plan_finish(uint64_t handle, uint64_t* out);
 int zk_msm_plan_windows(uint64_t handle, int* window_bits, int* n_windows);
+/* the window width and count a plan over n points will use (window_bits 0 = automatic), without creating one: what a
+ * rank needs to pick its share before zk_msm_plan_create_range */
+int zk_msm_window_layout(int curve, uint64_t n, int window_bits, int* window_bits_out, int* n_windows);
 /* milliseconds of the stages of the last zk_msm_plan_run on this plan, measured with HIP events on
  * the launch stream(s): [0] digits+sort, [1] bucket accumulation (dominant kernel; summed over its launches),
  * [2] bucket combination + reduction + D2H, [3] host tail, [4] total.  Returns the number of floats written. */

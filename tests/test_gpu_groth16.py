@@ -164,9 +164,9 @@ def test_groth16_bls12_381_chain_2_10(gpu):
     assert len(proof.to_bytes()) == 192 and g.verify(proof, w[:2])
 
 
-@pytest.mark.parametrize("curve,log_n", [("BN254", 20), ("BLS12_381", 20), ("BLS12_381", 22)])
+@pytest.mark.parametrize("curve,log_n", [("BN254", 20), ("BLS12_381", 20), ("BLS12_381", 22), ("BLS12_381", 23)])
 def test_full_size_proof_equals_committed_closed_form(gpu, curve, log_n):
-    """BASELINE config 4 (BN254, 2^20 constraints) and the config-5 circuit (BLS12-381) at 2^20 and 2^22: the proof bytes of
+    """BASELINE config 4 (BN254, 2^20 constraints) and the config-5 circuit (BLS12-381) at 2^20, 2^22 and its full 2^23: the proof bytes of
     the benchmark chain circuit equal the closed-form proof computed as discrete logarithms by the definitional oracle
     (tests/golden/groth16_vectors.json, gen_groth16_golden.py: no FFT, no MSM).  Limb-array witnesses and, at 2^20 BN254, the
     reference API's list[int] witnesses; the proof also passes the product's pairing verifier."""
