@@ -179,10 +179,22 @@ def point_limbs(cid, group):
 
 # ---- int <-> limb marshalling (the reference marshals Python ints through pyo3 BigUint) ----
 
+try:  # CPython helper built beside libzkmi.so (csrc/pyints.c); marshalling only
+    from . import _pyints
+except ImportError:  # pragma: no cover - e.g. a different interpreter than the one it was built for
+    _pyints = None
+
+
 def ints_to_limbs(vals, words=4, modulus=None):
     """list of non-negative ints -> (n, words) uint64, little-endian limbs.  Negative ints raise
     OverflowError, as pyo3's BigUint extraction does in the reference; with `modulus` values are
     reduced first, which is what `Fr::from(BigUint)` does (src/bn254/curve.rs:359)."""
+    if _pyints is not None:
+        if not isinstance(vals, (list, tuple)):
+            vals = list(vals)
+        out = np.empty((len(vals), words), dtype=np.uint64)
+        _pyints.ints_to_limbs(vals, words, modulus, out)
+        return out
     nbytes = 8 * words
     chunks = []
     for v in vals:
@@ -198,6 +210,8 @@ def ints_to_limbs(vals, words=4, modulus=None):
 def limbs_to_ints(arr):
     arr = np.ascontiguousarray(arr, dtype=np.uint64)
     words = arr.shape[-1]
+    if _pyints is not None:
+        return _pyints.limbs_to_ints(arr, words)
     raw = arr.tobytes()
     step = 8 * words
     return [int.from_bytes(raw[i:i + step], "little") for i in range(0, len(raw), step)]
