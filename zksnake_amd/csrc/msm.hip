@@ -115,7 +115,7 @@ int zk_msm_window_layout(int curve, uint64_t n, int window_bits, int* window_bit
         c = lg >= 16 ? 16 : lg - 2;
         if (c < 4) c = 4;
     }
-    if (c < 2 || c > 16) return fail(ZK_ERR_ARG, "window bits must be in [2, 16]");
+    if (c < 2 || c > 20) return fail(ZK_ERR_ARG, "window bits must be in [2, 20]");
     const int bits = curve == ZK_CURVE_BN254 ? BnFrParams::BITS : BlsFrParams::BITS;
     *window_bits_out = c;
     *n_windows = (bits + 1 + c - 1) / c;

@@ -127,9 +127,27 @@ struct DigitBias {
     uint32_t v[13];  // bias limbs (up to 12 + 1)
 };
 
-template <class FrP>
+// eight consecutive digits of a row as 32-bit values (rows are padded to 8 digits and 16-byte aligned)
+template <class DIG>
+__device__ __forceinline__ void load8_digits(const DIG* p, uint32_t* v);
+template <>
+__device__ __forceinline__ void load8_digits<uint16_t>(const uint16_t* p, uint32_t* v) {
+    const uint4 pk = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+}
+template <>
+__device__ __forceinline__ void load8_digits<uint32_t>(const uint32_t* p, uint32_t* v) {
+    const uint4 a = reinterpret_cast<const uint4*>(p)[0], b = reinterpret_cast<const uint4*>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// DIG = uint16_t for windows up to 16 bits, uint32_t for the wider windows of fixed-base plans
+template <class FrP, class DIG>
 __global__ void digits_kernel(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t dstride, int c, int w_first, int w_count,
-                              DigitBias bias, uint16_t* __restrict__ dig, uint32_t* __restrict__ big_count) {
+                              DigitBias bias, DIG* __restrict__ dig, uint32_t* __restrict__ big_count) {
     constexpr int N = FrP::W;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) big_count[0] = big_count[1] = 0;  // consumed by runs_scan_block_kernel later in the same stream
@@ -158,7 +176,7 @@ __global__ void digits_kernel(const uint32_t* __restrict__ scalars, uint32_t n, 
         uint64_t two = (uint64_t)s[word];
         if (word + 1 <= N) two |= (uint64_t)s[word + 1] << 32;
         uint32_t u = (uint32_t)(two >> off) & mask;
-        dig[(size_t)w * dstride + i] = (uint16_t)u;  // rows padded to 8 digits: 16-byte aligned vector reads
+        dig[(size_t)w * dstride + i] = (DIG)u;  // rows padded to 8 digits: 16-byte aligned vector reads
     }
 }
 
@@ -359,7 +377,8 @@ __device__ __forceinline__ uint32_t lds_count(uint32_t* counter, uint32_t idx) {
     return atomicAdd(&counter[idx], 1u);
 }
 
-static __global__ __launch_bounds__(SORT_THREADS) void hist_hi_kernel(const uint16_t* __restrict__ dig, uint32_t n, uint32_t dstride, int c,
+template <class DIG>
+static __global__ __launch_bounds__(SORT_THREADS) void hist_hi_kernel(const DIG* __restrict__ dig, uint32_t n, uint32_t dstride, int c,
                                                                       int w_first, int nchunk, uint32_t chunk_len, int fine_log,
                                                                       uint32_t* __restrict__ hist) {
     extern __shared__ uint32_t lds[];
@@ -369,14 +388,14 @@ static __global__ __launch_bounds__(SORT_THREADS) void hist_hi_kernel(const uint
     __syncthreads();
     uint32_t lo = chunk * chunk_len, hi = lo + chunk_len;
     if (hi > n) hi = n;
-    const uint16_t* d = dig + (size_t)(w_first + wl) * dstride;
-    // chunk_len is a multiple of 8 and the digit rows are 16-byte aligned: eight digits per lane and load
+    const DIG* d = dig + (size_t)(w_first + wl) * dstride;
+    // chunk_len is a multiple of 8 and the digit rows are 16-byte aligned: eight digits per lane
     for (uint32_t i = lo + threadIdx.x * 8; i < hi; i += SORT_THREADS * 8) {
-        const uint4 pk = *reinterpret_cast<const uint4*>(d + i);
-        const uint32_t wds[4] = {pk.x, pk.y, pk.z, pk.w};
+        uint32_t dg[8];
+        load8_digits<DIG>(d + i, dg);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            int v = (int)((wds[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu) - (int)B;
+            int v = (int)dg[k] - (int)B;
             if (i + k < hi && v != 0) (void)lds_count(lds, ((uint32_t)(v < 0 ? -v : v) - 1) >> fine_log);
         }
     }
@@ -463,6 +482,81 @@ static __global__ __launch_bounds__(1024) void bins_scan_kernel(uint32_t* __rest
     }
 }
 
+// The same in three launches for large tables (fixed-base plans: up to 4096 bins x ~250 sub-histograms = 1 M counters, 0.2 ms
+// in one workgroup): a grid of workgroups of 64 bins x 16 slices of the sub-histograms.
+constexpr int BINS_SLICES = 16;
+static __global__ __launch_bounds__(1024) void bins_partial_kernel(const uint32_t* __restrict__ hist, int subs, uint32_t NB, uint32_t pairs,
+                                                                   uint32_t* __restrict__ slice_sums, uint32_t* __restrict__ tot) {
+    __shared__ uint32_t sh[BINS_SLICES][64];
+    const uint32_t lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const uint32_t p = blockIdx.x * 64 + lane;
+    const uint32_t slice_len = ((uint32_t)subs + BINS_SLICES - 1) / BINS_SLICES;
+    uint32_t t = 0;
+    if (p < pairs) {
+        const uint32_t set = p / NB, bin = p % NB;
+        const uint32_t ch0 = sl * slice_len, ch1 = min((uint32_t)subs, ch0 + slice_len);
+#pragma unroll 4
+        for (uint32_t ch = ch0; ch < ch1; ++ch) t += hist[((size_t)set * subs + ch) * NB + bin];
+        slice_sums[(size_t)p * BINS_SLICES + sl] = t;
+    }
+    sh[sl][lane] = t;
+    __syncthreads();
+    if (sl == 0 && p < pairs) {
+        uint32_t a = 0;
+#pragma unroll
+        for (int k = 0; k < BINS_SLICES; ++k) a += sh[k][lane];
+        tot[p] = a;
+    }
+}
+// exclusive scan of tot[0 .. pairs), pairs <= 4096, one workgroup
+static __global__ __launch_bounds__(1024) void bins_scan_tot_kernel(const uint32_t* __restrict__ tot, uint32_t pairs,
+                                                                    uint32_t* __restrict__ bin_start, uint32_t* __restrict__ total_out) {
+    __shared__ uint32_t sums[1024];
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t p = threadIdx.x * 4 + k;
+        v[k] = p < pairs ? tot[p] : 0u;
+        sum += v[k];
+    }
+    sums[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        uint32_t o = (int)threadIdx.x >= d ? sums[threadIdx.x - d] : 0u;
+        __syncthreads();
+        sums[threadIdx.x] += o;
+        __syncthreads();
+    }
+    uint32_t run = sums[threadIdx.x] - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t p = threadIdx.x * 4 + k;
+        if (p < pairs) bin_start[p] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 1023) {
+        bin_start[pairs] = sums[1023];
+        *total_out = sums[1023];
+    }
+}
+static __global__ __launch_bounds__(1024) void bins_prefix_kernel(uint32_t* __restrict__ hist, int subs, uint32_t NB, uint32_t pairs,
+                                                                  const uint32_t* __restrict__ slice_sums, const uint32_t* __restrict__ bin_start) {
+    const uint32_t lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const uint32_t p = blockIdx.x * 64 + lane;
+    if (p >= pairs) return;
+    const uint32_t slice_len = ((uint32_t)subs + BINS_SLICES - 1) / BINS_SLICES;
+    const uint32_t set = p / NB, bin = p % NB;
+    uint32_t run = bin_start[p];
+    for (uint32_t k = 0; k < sl; ++k) run += slice_sums[(size_t)p * BINS_SLICES + k];
+    const uint32_t ch0 = sl * slice_len, ch1 = min((uint32_t)subs, ch0 + slice_len);
+    for (uint32_t ch = ch0; ch < ch1; ++ch) {
+        const size_t idx = ((size_t)set * subs + ch) * NB + bin;
+        const uint32_t t = hist[idx];
+        hist[idx] = run;
+        run += t;
+    }
+}
+
 // Level A with the output staged through LDS: the chunk is processed in tiles of 8192 entries (one 16-byte digit
 // load per lane); a tile is counted and ranked per bin in LDS, the bin counts are scanned (every wave its share of the
 // bins, then the 16 wave totals), the entries are placed bin-sorted into an LDS buffer and written out run by run, so
@@ -470,7 +564,8 @@ static __global__ __launch_bounds__(1024) void bins_scan_kernel(uint32_t* __rest
 // request rate.  Dynamic LDS: buf[8192] u32 | tcnt, toff, gcur [NBP] u32 | slot_bin[8192] u16, NBP = bins padded to 128.
 constexpr uint32_t SCATTER_TILE = SORT_THREADS * 8;
 
-static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_staged_kernel(const uint16_t* __restrict__ dig, uint32_t n, uint32_t dstride, int c,
+template <class DIG>
+static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_staged_kernel(const DIG* __restrict__ dig, uint32_t n, uint32_t dstride, int c,
                                                                                 int w_first, int nchunk, uint32_t chunk_len, int fine_log,
                                                                                 int shared_buckets, uint32_t table_stride, int table_w0,
                                                                                 const uint32_t* __restrict__ offsets,
@@ -479,7 +574,7 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_staged_kernel(
     __shared__ uint32_t wave_tot[SORT_THREADS / 64];
     const uint32_t B = 1u << (c - 1), NB = B >> fine_log;
     const uint32_t NBP = (NB + 127) & ~127u;          // multiple of 2 bins x 64 lanes
-    const uint32_t per_wave = NBP / (SORT_THREADS / 64);  // bins scanned by one wave: <= 128
+    const uint32_t per_wave = NBP / (SORT_THREADS / 64);  // bins scanned by one wave: <= 256 (NBP <= 4096)
     uint32_t* buf = lds;
     uint32_t* tcnt = lds + SCATTER_TILE;
     uint32_t* toff = tcnt + NBP;
@@ -495,19 +590,18 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_staged_kernel(
     __syncthreads();
     uint32_t lo = chunk * chunk_len, hi = lo + chunk_len;
     if (hi > n) hi = n;
-    const uint16_t* d = dig + (size_t)(w_first + wl) * dstride;
+    const DIG* d = dig + (size_t)(w_first + wl) * dstride;
     const uint32_t ref_base = shared_buckets ? (uint32_t)(w_first + wl - table_w0) * table_stride : 0;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (uint32_t base = lo; base < hi; base += SCATTER_TILE) {
         const uint32_t i = base + threadIdx.x * 8;
         uint32_t val[8], rank[8];
         uint16_t bin[8];
-        uint4 pk = make_uint4(0, 0, 0, 0);
-        if (i < hi) pk = *reinterpret_cast<const uint4*>(d + i);
-        const uint32_t wds[4] = {pk.x, pk.y, pk.z, pk.w};
+        uint32_t dg[8] = {B, B, B, B, B, B, B, B};
+        if (i < hi) load8_digits<DIG>(d + i, dg);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            int v = (int)((wds[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu) - (int)B;
+            int v = (int)dg[k] - (int)B;
             bin[k] = 0xFFFF;
             if (i + k < hi && v != 0) {
                 const uint32_t b = (uint32_t)(v < 0 ? -v : v) - 1;
@@ -517,15 +611,16 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_staged_kernel(
             }
         }
         __syncthreads();
-        // exclusive scan of the tile's bin counts: wave w scans bins [w per_wave, (w+1) per_wave), two per lane
-        uint32_t c0 = 0, c1 = 0, incl = 0;
+        // exclusive scan of the tile's bin counts: wave w scans bins [w per_wave, (w+1) per_wave), per_wave / 64 = up to
+        // four consecutive bins per lane (NBP <= 4096 coarse bins)
+        const uint32_t bpl = (per_wave + 63) / 64;
+        uint32_t cb[4] = {0, 0, 0, 0}, incl = 0;
         {
-            const uint32_t b0 = wave * per_wave + lane * 2;
-            if (lane * 2 < per_wave) {
-                c0 = tcnt[b0];
-                c1 = tcnt[b0 + 1];
-            }
-            incl = c0 + c1;
+            const uint32_t b0 = wave * per_wave + lane * bpl;
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t)
+                if (t < bpl && lane * bpl + t < per_wave) cb[t] = tcnt[b0 + t];
+            incl = cb[0] + cb[1] + cb[2] + cb[3];
 #pragma unroll
             for (int dd = 1; dd < 64; dd <<= 1) {
                 uint32_t o = __shfl_up(incl, dd, 64);
@@ -535,13 +630,16 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_staged_kernel(
         }
         __syncthreads();
         {
-            uint32_t before = 0;
-            for (uint32_t w2 = 0; w2 < wave; ++w2) before += wave_tot[w2];
-            const uint32_t b0 = wave * per_wave + lane * 2;
-            if (lane * 2 < per_wave) {
-                toff[b0] = before + incl - c0 - c1;
-                toff[b0 + 1] = before + incl - c1;
-            }
+            uint32_t run = 0;
+            for (uint32_t w2 = 0; w2 < wave; ++w2) run += wave_tot[w2];
+            run += incl - (cb[0] + cb[1] + cb[2] + cb[3]);
+            const uint32_t b0 = wave * per_wave + lane * bpl;
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t)
+                if (t < bpl && lane * bpl + t < per_wave) {
+                    toff[b0 + t] = run;
+                    run += cb[t];
+                }
         }
         __syncthreads();
 #pragma unroll
@@ -1071,13 +1169,16 @@ struct MsmPlan : MsmPlanBase {
     static constexpr int AW = 2 * F::LIMBS;
     static constexpr int XW = 4 * F::LIMBS;
     static constexpr uint64_t SEG_TARGET_LANES = 256ull * 1024;  // 4 waves per SIMD on 256 CUs
+    static constexpr int MAX_C = 20;           // widest window (fixed-base plans; digits are then 32-bit)
+    static constexpr int WIDE_C_DEFAULT = 20;  // measured at 2^20 BN254 G1: see DESIGN.md
+    bool wide = false;                         // c > 16: 32-bit digits, two-level sort only
 
     // device workspace of one run (stages 2..7)
     struct Work {
         uint32_t *hist = nullptr, *total = nullptr, *bstart = nullptr, *sstart = nullptr;
         uint32_t *bsums = nullptr, *grand = nullptr, *big_list = nullptr, *big_count = nullptr;
         uint32_t *sorted = nullptr, *partials = nullptr, *buckets = nullptr, *rows = nullptr, *fin = nullptr;
-        uint32_t *tmp_ref = nullptr, *bin_start = nullptr;  // two-level sort
+        uint32_t *tmp_ref = nullptr, *bin_start = nullptr, *slice_sums = nullptr, *bin_tot = nullptr;  // two-level sort
         hipEvent_t ev_begin = nullptr, ev_acc0 = nullptr, ev_acc1 = nullptr, ev_done = nullptr;
         int w_first = 0, w_count = 0;  // windows of the run in flight
         uint32_t groups = 0;           // bucket sets of the run in flight
@@ -1094,13 +1195,13 @@ struct MsmPlan : MsmPlanBase {
     std::shared_ptr<DeviceBlock> bases_block;  // the (table of) bases: shared by the clones of a plan
     uint32_t* d_bases = nullptr;
     uint32_t* d_scalars = nullptr;
-    uint16_t* d_dig = nullptr;
+    void* d_dig = nullptr;  // windows x (n + 8) digits, uint16_t (c <= 16) or uint32_t
     uint32_t* h_final = nullptr;  // pinned: (S, T) per weighted-sum block
     hipEvent_t ev_start = nullptr, ev_digits = nullptr, ev_end = nullptr;
 
     ~MsmPlan() override {
         void* bufs[] = {ws.hist, ws.total, ws.bstart, ws.sstart, ws.bsums, ws.grand, ws.big_list, ws.big_count,
-                        ws.sorted, ws.partials, ws.buckets, ws.rows, ws.fin, ws.tmp_ref, ws.bin_start,
+                        ws.sorted, ws.partials, ws.buckets, ws.rows, ws.fin, ws.tmp_ref, ws.bin_start, ws.slice_sums, ws.bin_tot,
                         d_scalars, d_dig};
         for (void* q : bufs) if (q) (void)hipFree(q);
         if (h_final) (void)hipHostFree(h_final);
@@ -1118,7 +1219,26 @@ struct MsmPlan : MsmPlanBase {
         if (n_points == 0 || n_points > (1ull << 26)) return fail(ZK_ERR_ARG, "MSM size must be in [1, 2^26]");
         n = n_points;
         c = window_bits > 0 ? window_bits : pick_window_bits(n);
-        if (c < 2 || c > 16) return fail(ZK_ERR_ARG, "window bits must be in [2, 16]");
+        if (window_bits <= 0 && pre && win_count <= 0) {
+            // fixed-base plans over all windows: one shared bucket set makes wider windows affordable (13 windows of
+            // 20 bits instead of 16 of 16: 19 % fewer additions) as long as a table reference still fits the 32-bit
+            // sort entry.  Window-sharded plans keep 16 windows, which split evenly over 2, 4 or 8 ranks.
+            static const int pre_c = getenv("ZKMI_PRE_C") ? atoi(getenv("ZKMI_PRE_C")) : 0;
+            static const bool no_two_level = getenv("ZKMI_NO_TWO_LEVEL") != nullptr;  // wide windows exist in the two-level sort only
+            // Candidates whose TOP window is at least half full: all windows feed one bucket set, and a short top window
+            // (18 bits: 3 scalar bits left for it) would pile its n entries into a handful of buckets of one coarse bin.
+            const int cands[3] = {pre_c ? pre_c : WIDE_C_DEFAULT, 17, 0};
+            for (int k = 0; !no_two_level && cands[k] > 16; ++k) {
+                const int cand = cands[k];
+                const uint64_t w = (FrP::BITS + 1 + cand - 1) / cand;
+                const int top_bits = FrP::BITS + 1 - (int)(w - 1) * cand;
+                if (n >= (1ull << 18) && w < 16 && (2 * top_bits >= cand || pre_c) && w * n <= (1ull << (31 - (cand - 13)))) { c = cand; break; }
+                if (pre_c) break;
+            }
+        }
+        if (c < 2 || c > MAX_C) return fail(ZK_ERR_ARG, "window bits must be in [2, 20]");
+        if (c > 16 && !pre) return fail(ZK_ERR_ARG, "windows wider than 16 bits need a fixed-base plan (ZK_MSM_PRECOMPUTE)");
+        wide = c > 16;
         nwin = (FrP::BITS + 1 + c - 1) / c;
         if (win_count <= 0) { win_first = 0; win_count = nwin; }
         if (win_first < 0 || win_first + win_count > nwin) return fail(ZK_ERR_ARG, "window range out of bounds");
@@ -1126,10 +1246,10 @@ struct MsmPlan : MsmPlanBase {
         pw_count = win_count;
         B = 1u << (c - 1);
         int rl = (c - 1 + 1) / 2;
-        if (rl > 8) rl = 8;
+        if (rl > 8 && !wide) rl = 8;
         R = 1u << rl;
         C = B / R;
-        if (C > 256) return fail(ZK_ERR_ARG, "window too wide for the reduction stage");
+        if (C > 1024 || R > 1024) return fail(ZK_ERR_ARG, "window too wide for the reduction stage");
         bpr = (R + WS_BLOCK - 1) / WS_BLOCK;
         bpc = (C + WS_BLOCK - 1) / WS_BLOCK;
         // bucket ranges (general mode, small inputs): about 256 sort workgroups in total, at least 64 buckets each
@@ -1179,7 +1299,8 @@ struct MsmPlan : MsmPlanBase {
             }
         }
         ZK_HIP(hipMalloc(&d_scalars, n * FrP::W * 4));
-        ZK_HIP(hipMalloc(&d_dig, (size_t)pw_count * (n + 8) * 2));
+        ZK_HIP(hipMalloc(&d_dig, (size_t)pw_count * (n + 8) * (wide ? 4 : 2)));
+        if (wide && !two_level_ok()) return fail(ZK_ERR_ARG, "this size does not fit the two-level sort that wide windows need");
         const uint64_t max_sets = pre ? 1ull : (uint64_t)pw_count;
         ZK_HIP(hipHostMalloc(&h_final, (size_t)max_sets * (bpr + bpc) * 2 * XW * 4));
         for (hipEvent_t* e : {&ev_start, &ev_digits, &ev_end}) ZK_HIP(hipEventCreate(e));
@@ -1188,7 +1309,8 @@ struct MsmPlan : MsmPlanBase {
             // a window-range run picks its own (shorter) segments: at most SEG_TARGET_LANES of them, or entries / 8
             const uint32_t seg_full = pick_seg_len(entries);
             const uint64_t max_segs = std::max<uint64_t>(entries / seg_full, std::min<uint64_t>(entries / 8, SEG_TARGET_LANES)) + keys + 8;
-            ZK_HIP(hipMalloc(&ws.hist, (size_t)std::max<uint64_t>(256, pw_count) * B * 4));  // windows x chunks <= max(256, windows)
+            // windows x chunks <= max(256, windows) sub-histograms: of all B buckets (one-level sort) or of the coarse bins only
+            ZK_HIP(hipMalloc(&ws.hist, (size_t)std::max<uint64_t>(256, pw_count) * (wide ? (B >> fine_log_for(n)) : B) * 4));
             ZK_HIP(hipMalloc(&ws.total, keys * 4));
             ZK_HIP(hipMalloc(&ws.bstart, (keys + 1) * 4));
             ZK_HIP(hipMalloc(&ws.sstart, (keys + 1) * 4));
@@ -1200,6 +1322,8 @@ struct MsmPlan : MsmPlanBase {
             if (two_level_ok()) {
                 ZK_HIP(hipMalloc(&ws.tmp_ref, entries * 4));
                 ZK_HIP(hipMalloc(&ws.bin_start, (max_sets * (B >> fine_log_for(n)) + 1) * 4));
+                ZK_HIP(hipMalloc(&ws.slice_sums, 4096 * BINS_SLICES * 4));
+                ZK_HIP(hipMalloc(&ws.bin_tot, 4096 * 4));
             }
             ZK_HIP(hipMalloc(&ws.partials, max_segs * XW * 4));
             ZK_HIP(hipMalloc(&ws.buckets, keys * XW * 4));
@@ -1208,12 +1332,13 @@ struct MsmPlan : MsmPlanBase {
             for (hipEvent_t* e : {&ws.ev_begin, &ws.ev_acc0, &ws.ev_acc1, &ws.ev_done}) ZK_HIP(hipEventCreate(e));
         }
         // LDS above 64 KiB needs the opt-in
-        int lds_bytes = (int)(B * 4);
+        int lds_bytes = (int)((wide ? (1u << 15) : B) * 4);  // the one-level kernels never run for wide windows
         ZK_HIP(hipFuncSetAttribute((const void*)hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         ZK_HIP(hipFuncSetAttribute((const void*)scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         ZK_HIP(hipFuncSetAttribute((const void*)hist_range_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         ZK_HIP(hipFuncSetAttribute((const void*)scatter_range_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        ZK_HIP(hipFuncSetAttribute((const void*)scatter_hi_staged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        ZK_HIP(hipFuncSetAttribute((const void*)scatter_hi_staged_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        ZK_HIP(hipFuncSetAttribute((const void*)scatter_hi_staged_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         ZK_HIP(hipFuncSetAttribute((const void*)sort_lo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
         ZK_HIP(hipFuncSetAttribute((const void*)weighted_sum_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(HalfRegs<F>::COUNT * HS_THREADS * 4)));
@@ -1248,6 +1373,10 @@ struct MsmPlan : MsmPlanBase {
         // and the coarse bins are shared by all windows -- more, smaller bins keep level B parallel
         const uint64_t refs = pre ? (uint64_t)pw_count * points : points;
         const uint64_t sets = pre ? 1 : (uint64_t)pw_count;
+        if (wide) {
+            const int f = c - 13;  // 4096 coarse bins
+            return refs <= (1ull << (31 - f)) ? f : 0;
+        }
         const int f_hi = pre ? 5 : FINE_LOG_MAX, f_lo = pre ? 4 : FINE_LOG_MAX - 1;
         for (int f = f_hi; f >= f_lo; --f)
             if (refs <= (1ull << (31 - f)) && c - 1 >= f + 2 && sets * (B >> f) <= 4096) return f;
@@ -1288,22 +1417,34 @@ struct MsmPlan : MsmPlanBase {
         const uint32_t ch_len = (m + nchunk - 1) / nchunk;
         ZK_HIP(hipEventRecord(l.ev_begin, st));
         // digit rows are stored relative to the plan's first window; the kernels index them with absolute windows
-        const uint16_t* d_dig = reinterpret_cast<const uint16_t*>(reinterpret_cast<uintptr_t>(this->d_dig) - (uintptr_t)pw_first * dstride * 2);
+        const uintptr_t dig_base = reinterpret_cast<uintptr_t>(this->d_dig) - (uintptr_t)pw_first * dstride * (wide ? 4 : 2);
+        const uint16_t* d_dig = reinterpret_cast<const uint16_t*>(dig_base);
+        const uint32_t* d_dig32 = reinterpret_cast<const uint32_t*>(dig_base);
         // general mode, small inputs: bucket-range partition (measured faster up to 2^18); otherwise the two-level sort
-        const bool ranged = !pre && m < (1u << 19);
+        const bool ranged = !pre && !wide && m < (1u << 19);
         const bool two_level = !ranged && l.tmp_ref != nullptr;
         if (two_level) {
             const int fl = fine_log_for(n);
             const uint32_t NB = B >> fl;
             const uint32_t ch8 = (ch_len + 7) & ~7u;  // the kernels read eight digits per load
-            hipLaunchKernelGGL(hist_hi_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), NB * 4, st, d_dig, m, dstride, c, w_first, nchunk, ch8, fl, l.hist);
+            if (wide) hipLaunchKernelGGL(hist_hi_kernel<uint32_t>, dim3(w_count * nchunk), dim3(SORT_THREADS), NB * 4, st, d_dig32, m, dstride, c, w_first, nchunk, ch8, fl, l.hist);
+            else hipLaunchKernelGGL(hist_hi_kernel<uint16_t>, dim3(w_count * nchunk), dim3(SORT_THREADS), NB * 4, st, d_dig, m, dstride, c, w_first, nchunk, ch8, fl, l.hist);
             // fixed-base mode: one bucket set fed by all (window, chunk) sub-histograms; general mode: one set per window
             const int sets = pre ? 1 : w_count, subs = pre ? w_count * nchunk : nchunk;
-            hipLaunchKernelGGL(bins_scan_kernel, dim3(1), dim3(1024), 0, st, l.hist, sets, subs, NB, l.bin_start, l.bstart + n_keys);
+            const uint32_t pairs = (uint32_t)sets * NB;
+            if ((uint64_t)pairs * subs >= (1u << 17)) {
+                const unsigned bb = (pairs + 63) / 64;
+                hipLaunchKernelGGL(bins_partial_kernel, dim3(bb), dim3(1024), 0, st, l.hist, subs, NB, pairs, l.slice_sums, l.bin_tot);
+                hipLaunchKernelGGL(bins_scan_tot_kernel, dim3(1), dim3(1024), 0, st, l.bin_tot, pairs, l.bin_start, l.bstart + n_keys);
+                hipLaunchKernelGGL(bins_prefix_kernel, dim3(bb), dim3(1024), 0, st, l.hist, subs, NB, pairs, l.slice_sums, l.bin_start);
+            } else {
+                hipLaunchKernelGGL(bins_scan_kernel, dim3(1), dim3(1024), 0, st, l.hist, sets, subs, NB, l.bin_start, l.bstart + n_keys);
+            }
             {
                 const uint32_t NBP = (NB + 127) & ~127u;
                 const size_t lds_a = (size_t)SCATTER_TILE * 4 + (size_t)NBP * 12 + (size_t)SCATTER_TILE * 2;
-                hipLaunchKernelGGL(scatter_hi_staged_kernel, dim3(w_count * nchunk), dim3(SORT_THREADS), lds_a, st, d_dig, m, dstride, c, w_first, nchunk, ch8, fl, pre ? 1 : 0, (uint32_t)n, pw_first, l.hist, l.tmp_ref);
+                if (wide) hipLaunchKernelGGL(scatter_hi_staged_kernel<uint32_t>, dim3(w_count * nchunk), dim3(SORT_THREADS), lds_a, st, d_dig32, m, dstride, c, w_first, nchunk, ch8, fl, pre ? 1 : 0, (uint32_t)n, pw_first, l.hist, l.tmp_ref);
+                else hipLaunchKernelGGL(scatter_hi_staged_kernel<uint16_t>, dim3(w_count * nchunk), dim3(SORT_THREADS), lds_a, st, d_dig, m, dstride, c, w_first, nchunk, ch8, fl, pre ? 1 : 0, (uint32_t)n, pw_first, l.hist, l.tmp_ref);
             }
             // LDS stage of level B: 1.5x the expected entries of a coarse bin, capped at 96 KiB
             uint64_t expect = ((uint64_t)w_count * m) / ((uint64_t)sets * NB);
@@ -1401,8 +1542,11 @@ struct MsmPlan : MsmPlanBase {
                 int bit = w * c + (c - 1);
                 bias.v[bit >> 5] |= 1u << (bit & 31);
             }
-            hipLaunchKernelGGL(digits_kernel<FrP>, dim3((m + 255) / 256), dim3(256), 0, st, sc, m, dstride, c, w_first, w_count, bias,
-                               reinterpret_cast<uint16_t*>(reinterpret_cast<uintptr_t>(d_dig) - (uintptr_t)pw_first * dstride * 2), ws.big_count);
+            const uintptr_t dig_base = reinterpret_cast<uintptr_t>(d_dig) - (uintptr_t)pw_first * dstride * (wide ? 4 : 2);
+            if (wide) hipLaunchKernelGGL((digits_kernel<FrP, uint32_t>), dim3((m + 255) / 256), dim3(256), 0, st, sc, m, dstride, c, w_first, w_count, bias,
+                                         reinterpret_cast<uint32_t*>(dig_base), ws.big_count);
+            else hipLaunchKernelGGL((digits_kernel<FrP, uint16_t>), dim3((m + 255) / 256), dim3(256), 0, st, sc, m, dstride, c, w_first, w_count, bias,
+                                    reinterpret_cast<uint16_t*>(dig_base), ws.big_count);
             ZK_HIP(hipEventRecord(ev_digits, st));
             ws.w_first = w_first;
             ws.w_count = w_count;
@@ -1436,21 +1580,25 @@ struct MsmPlan : MsmPlanBase {
             auto pt = [](const uint32_t* p) { return HF::xyzz_from_device(p); };
             bool first_set = true;
             for (int g = groups - 1; g >= 0; --g) {
+                // X = sum_k k T_k as a running sum of suffixes (from the top block down): two additions per block
                 XYZZ<HF> sum_s = xyzz_inf<HF>(), sum_t = xyzz_inf<HF>(), x_r = xyzz_inf<HF>();
-                for (uint32_t k = 0; k < bpr; ++k) {
+                for (int k = (int)bpr - 1; k >= 0; --k) {
                     const uint32_t* q = rows_fin + ((size_t)g * bpr + k) * 2 * XW;
                     sum_s = xyzz_add<HF>(sum_s, pt(q));
-                    XYZZ<HF> t = pt(q + XW);
-                    sum_t = xyzz_add<HF>(sum_t, t);
-                    for (uint32_t j = 0; j < k; ++j) x_r = xyzz_add<HF>(x_r, t);  // k T_k, k <= 1 in practice
+                    if (k > 0) {
+                        sum_t = xyzz_add<HF>(sum_t, pt(q + XW));  // T_k + .. + T_top
+                        x_r = xyzz_add<HF>(x_r, sum_t);
+                    } else {
+                        sum_t = xyzz_add<HF>(sum_t, pt(q + XW));
+                    }
                 }
-                XYZZ<HF> sum_sc = xyzz_inf<HF>(), x_c = xyzz_inf<HF>();
-                for (uint32_t k = 0; k < bpc; ++k) {
+                XYZZ<HF> sum_sc = xyzz_inf<HF>(), x_c = xyzz_inf<HF>(), suf_c = xyzz_inf<HF>();
+                for (int k = (int)bpc - 1; k >= 0; --k) {
                     const uint32_t* q = cols_fin + ((size_t)g * bpc + k) * 2 * XW;
                     sum_sc = xyzz_add<HF>(sum_sc, pt(q));
-                    if (k) {
-                        XYZZ<HF> t = pt(q + XW);
-                        for (uint32_t j = 0; j < k; ++j) x_c = xyzz_add<HF>(x_c, t);
+                    if (k > 0) {
+                        suf_c = xyzz_add<HF>(suf_c, pt(q + XW));
+                        x_c = xyzz_add<HF>(x_c, suf_c);
                     }
                 }
                 // terms in descending order of their exponent; `at` = exponent the accumulator currently sits at

@@ -330,6 +330,7 @@ static int get_twiddles(int curve, int log_n, TwiddleSet* out, hipStream_t strea
 }
 
 static void free_scratch();
+static void free_coset_tables();
 static void free_twiddles() {
     std::lock_guard<std::mutex> lock(g_tw_mutex);
     for (auto& kv : g_twiddles) {
@@ -339,6 +340,7 @@ static void free_twiddles() {
     g_twiddles.clear();
     for (void* p : g_tw_retired) (void)hipFree(p);
     g_tw_retired.clear();
+    free_coset_tables();
 }
 
 // Scratch vectors of the transform, one set per stream (work on a stream is ordered, so reuse is safe); grow-only.
@@ -523,30 +525,128 @@ static int div_vanishing_host_impl(uint64_t n, uint64_t len, const uint64_t* coe
     return rc;
 }
 
+// ---- QAP quotient on a coset ------------------------------------------------------------------------------------
+// h = (u v - w) / (X^n - 1).  The reference multiplies u and v over the doubled domain and divides the 2n coefficients
+// (qap.py:51-67 -> mul_over_fft, divide_by_vanishing_poly).  The same polynomial costs less on a coset g H of the
+// n-point domain, where X^n - 1 is the CONSTANT g^n - 1: evaluate u, v, w there (three size-n transforms of the
+// coefficients scaled by g^i), form (u v - w) / (g^n - 1) point-wise and interpolate back (one inverse transform and a
+// scaling by g^-i): seven size-n transforms instead of three of size n and three of size 2n.  The quotient is exact iff
+// a_i b_i = c_i on the domain itself, which is checked directly on the evaluation vectors (the reference's "remainder
+// must be zero", qap.py:68-69).  g = the field's multiplicative generator (5 for BN254 Fr, 7 for BLS12-381 Fr).
+constexpr int COSET_SPLIT = 14;  // g^i = glo[i mod 2^14] * ghi[i >> 14]: two 512 KiB tables serve every size
+
+struct CosetTables {
+    uint32_t *lo = nullptr, *hi = nullptr, *lo_inv = nullptr, *hi_inv = nullptr;
+};
+static std::map<int, CosetTables> g_coset;  // per curve (under g_tw_mutex)
+static void free_coset_tables() {  // caller holds g_tw_mutex
+    for (auto& kv : g_coset)
+        for (uint32_t* p : {kv.second.lo, kv.second.hi, kv.second.lo_inv, kv.second.hi_inv}) (void)hipFree(p);
+    g_coset.clear();
+}
+
+template <class P>
+static Fp<P> coset_generator() {
+    uint32_t g[P::W] = {0};
+    g[0] = P::TWO_ADICITY == 28 ? 5u : 7u;  // BN254 Fr: 5 (two-adicity 28); BLS12-381 Fr: 7 (two-adicity 32)
+    return fp_from_canonical<P>(g);
+}
+
+template <class P>
+static int get_coset_tables(int curve, CosetTables* out, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_tw_mutex);
+    auto it = g_coset.find(curve);
+    if (it != g_coset.end()) { *out = it->second; return ZK_OK; }
+    CosetTables t;
+    const uint32_t cnt = 1u << COSET_SPLIT;
+    const size_t bytes = (size_t)cnt * P::W * 4;
+    for (uint32_t** p : {&t.lo, &t.hi, &t.lo_inv, &t.hi_inv}) ZK_HIP(hipMalloc(p, bytes));
+    Fp<P> g = coset_generator<P>(), gi = fp_inv<P>(g);
+    Fp<P> gs = g, gis = gi;
+    for (int k = 0; k < COSET_SPLIT; ++k) { gs = fp_sqr<P>(gs); gis = fp_sqr<P>(gis); }
+    hipLaunchKernelGGL(twiddle_kernel<P>, dim3(cnt / 256), dim3(256), 0, stream, t.lo, g, cnt);
+    hipLaunchKernelGGL(twiddle_kernel<P>, dim3(cnt / 256), dim3(256), 0, stream, t.hi, gs, cnt);
+    hipLaunchKernelGGL(twiddle_kernel<P>, dim3(cnt / 256), dim3(256), 0, stream, t.lo_inv, gi, cnt);
+    hipLaunchKernelGGL(twiddle_kernel<P>, dim3(cnt / 256), dim3(256), 0, stream, t.hi_inv, gis, cnt);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(stream));
+    g_coset[curve] = t;
+    *out = t;
+    return ZK_OK;
+}
+
+// out[i] = in[i] * g^(+-i) (canonical in and out; the tables hold Montgomery forms, so two products leave x * g^i)
+template <class P>
+__global__ void coset_mul_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
+                                 const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp<P> x = load_fr<P>(in + i * P::W);
+    x = fp_mul<P>(x, load_fr<P>(lo + (size_t)(i & ((1u << COSET_SPLIT) - 1)) * P::W));
+    x = fp_mul<P>(x, load_fr<P>(hi + (size_t)(i >> COSET_SPLIT) * P::W));
+    store_fr<P>(out + i * P::W, fp_reduce_full<P>(x));
+}
+
+// flag |= (a[i] * b[i] != c[i]) on the domain: the witness satisfies the constraints iff this never fires
+template <class P>
+__global__ void qap_eval_check_kernel(uint64_t n, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                      const uint32_t* __restrict__ c, int* nonzero) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // mont(a, b) = a b / R against mont(c, 1) = c / R
+    Fp<P> one = fp_zero<P>();
+    one.v[0] = 1;
+    Fp<P> r = fp_sub<P>(fp_mul<P>(load_fr<P>(a + i * P::W), load_fr<P>(b + i * P::W)), fp_mul<P>(load_fr<P>(c + i * P::W), one));
+    if (!fp_is_zero<P>(r)) atomicOr(nonzero, 1);
+}
+
+// out[i] = (u[i] v[i] - w[i]) * z, z given as z R^2 (so that mont(mont(u, v) - mont(w, 1), z R^2) = (u v - w) z)
+template <class P>
+__global__ void qap_quotient_kernel(uint64_t n, const uint32_t* __restrict__ u, const uint32_t* __restrict__ v,
+                                    const uint32_t* __restrict__ w, Fp<P> z_r2, uint32_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp<P> one = fp_zero<P>();
+    one.v[0] = 1;
+    Fp<P> d = fp_sub<P>(fp_mul<P>(load_fr<P>(u + i * P::W), load_fr<P>(v + i * P::W)), fp_mul<P>(load_fr<P>(w + i * P::W), one));
+    store_fr<P>(out + i * P::W, fp_reduce_full<P>(fp_mul<P>(d, z_r2)));
+}
+
 template <class P>
 static int qap_h_dev_impl(int curve, int log_n, uint32_t* a_u, uint32_t* b_v, const uint32_t* c, uint32_t* h,
                           uint32_t* work, int* divisible, hipStream_t stream) {
-    if (log_n + 1 > P::TWO_ADICITY) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
+    if (log_n > P::TWO_ADICITY) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
     const uint64_t n = 1ull << log_n;
     const size_t eb = P::W * 4;
-    uint32_t* U2 = work;
-    uint32_t* V2 = work + 2 * n * P::W;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    uint32_t* W0 = work;                     // w coefficients, then w on the coset
+    uint32_t* U1 = work + n * P::W;          // u on the coset, then the quotient's coset values
+    uint32_t* V1 = work + 2 * n * P::W;      // v on the coset
+    int* dflag = reinterpret_cast<int*>(work + 3 * n * P::W);
+    CosetTables ct;
     int rc;
+    if ((rc = get_coset_tables<P>(curve, &ct, stream))) return rc;
+    ZK_HIP(hipMemsetAsync(dflag, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(qap_eval_check_kernel<P>, dim3(blocks), dim3(256), 0, stream, n, a_u, b_v, c, dflag);
     if ((rc = ntt_dev_impl<P>(curve, 1, log_n, a_u, stream))) return rc;  // u
     if ((rc = ntt_dev_impl<P>(curve, 1, log_n, b_v, stream))) return rc;  // v
-    ZK_HIP(hipMemsetAsync(work, 0, 4 * n * eb, stream));
-    ZK_HIP(hipMemcpyAsync(U2, a_u, n * eb, hipMemcpyDeviceToDevice, stream));
-    ZK_HIP(hipMemcpyAsync(V2, b_v, n * eb, hipMemcpyDeviceToDevice, stream));
-    if ((rc = ntt_dev_impl<P>(curve, 0, log_n + 1, U2, stream))) return rc;
-    if ((rc = ntt_dev_impl<P>(curve, 0, log_n + 1, V2, stream))) return rc;
-    if ((rc = vec_op_dev_impl<P>(0, 2 * n, U2, V2, U2, stream))) return rc;
-    if ((rc = ntt_dev_impl<P>(curve, 1, log_n + 1, U2, stream))) return rc;  // uv coefficients
-    ZK_HIP(hipMemcpyAsync(V2, c, n * eb, hipMemcpyDeviceToDevice, stream));
-    if ((rc = ntt_dev_impl<P>(curve, 1, log_n, V2, stream))) return rc;      // w
-    int* dflag = reinterpret_cast<int*>(V2 + n * P::W);  // second half of V2 is free now
-    ZK_HIP(hipMemsetAsync(dflag, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(qap_check_kernel<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, U2, U2 + n * P::W, V2, dflag);
-    ZK_HIP(hipMemcpyAsync(h, U2 + n * P::W, n * eb, hipMemcpyDeviceToDevice, stream));
+    ZK_HIP(hipMemcpyAsync(W0, c, n * eb, hipMemcpyDeviceToDevice, stream));
+    if ((rc = ntt_dev_impl<P>(curve, 1, log_n, W0, stream))) return rc;   // w
+    hipLaunchKernelGGL(coset_mul_kernel<P>, dim3(blocks), dim3(256), 0, stream, a_u, U1, n, ct.lo, ct.hi);
+    hipLaunchKernelGGL(coset_mul_kernel<P>, dim3(blocks), dim3(256), 0, stream, b_v, V1, n, ct.lo, ct.hi);
+    hipLaunchKernelGGL(coset_mul_kernel<P>, dim3(blocks), dim3(256), 0, stream, W0, W0, n, ct.lo, ct.hi);
+    if ((rc = ntt_dev_impl<P>(curve, 0, log_n, U1, stream))) return rc;
+    if ((rc = ntt_dev_impl<P>(curve, 0, log_n, V1, stream))) return rc;
+    if ((rc = ntt_dev_impl<P>(curve, 0, log_n, W0, stream))) return rc;
+    // 1 / (g^n - 1), carried as z R^2
+    Fp<P> gn = coset_generator<P>();
+    for (int k = 0; k < log_n; ++k) gn = fp_sqr<P>(gn);
+    Fp<P> z = fp_inv<P>(fp_sub<P>(gn, fp_one<P>()));          // Montgomery form: z R
+    Fp<P> z_r2 = fp_mul<P>(z, fp_const<P>(P::R2));            // z R * R^2 / R = z R^2
+    hipLaunchKernelGGL(qap_quotient_kernel<P>, dim3(blocks), dim3(256), 0, stream, n, U1, V1, W0, z_r2, U1);
+    if ((rc = ntt_dev_impl<P>(curve, 1, log_n, U1, stream))) return rc;
+    hipLaunchKernelGGL(coset_mul_kernel<P>, dim3(blocks), dim3(256), 0, stream, U1, h, n, ct.lo_inv, ct.hi_inv);
+    ZK_HIP(hipGetLastError());
     int flag = 0;
     ZK_HIP(hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, stream));
     ZK_HIP(hipStreamSynchronize(stream));
