@@ -87,7 +87,11 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(c
     }
     __syncthreads();
 
-    for (int b = m - 1; b >= 0; --b) {
+    // Stages in pairs: a thread takes the four elements that differ in bits (b, b-1) of D, runs both stages on them
+    // in registers (four butterflies, three distinct twiddles) and writes them back: half the LDS traffic and half the
+    // barriers of one stage per round trip.  An odd stage count starts with a single radix-2 stage.
+    int b = m - 1;
+    if (m & 1) {
         const int s = rem - m + b;
         const int pos = b + q;
         const uint32_t* tws = tw + ((size_t)(1u << s) - 1) * W;
@@ -106,6 +110,46 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(c
             Fp<P> dif = fp_mul<P>(w, fp_sub_lazy<P>(x, y));  // (x - y + 4p) un-normalized: fine as a product operand
 #pragma unroll
             for (int l = 0; l < N; ++l) { lds[l * row + l0] = sum.v[l]; lds[l * row + l1] = dif.v[l]; }
+        }
+        __syncthreads();
+        --b;
+    }
+    for (; b >= 1; b -= 2) {
+        const int s = rem - m + b;          // upper stage of the pair; the lower one is s - 1
+        const int pos_lo = b - 1 + q;
+        const uint32_t* tw_hi = tw + ((size_t)(1u << s) - 1) * W;
+        const uint32_t* tw_lo = tw + ((size_t)(1u << (s - 1)) - 1) * W;
+        for (uint32_t u = threadIdx.x; u < (tile >> 2); u += NTT_THREADS) {
+            const uint32_t e00 = ((u >> pos_lo) << (pos_lo + 2)) | (u & ((1u << pos_lo) - 1));
+            const uint32_t e01 = e00 | (1u << pos_lo), e10 = e00 | (2u << pos_lo), e11 = e00 | (3u << pos_lo);
+            const uint32_t d0 = e00 >> q, r = e00 & qmask;
+            const uint32_t low = (rest0 | r) >> done;
+            const uint32_t j0 = ((d0 & ((1u << b) - 1)) << (rem - m)) | low;            // stage s, bit b-1 of D clear
+            const uint32_t j1 = j0 + ((1u << (b - 1)) << (rem - m));                    // stage s, bit b-1 set
+            const uint32_t j2 = ((d0 & ((1u << (b - 1)) - 1)) << (rem - m)) | low;      // stage s-1 (both pairs)
+            const uint32_t l00 = LIDX(e00), l01 = LIDX(e01), l10 = LIDX(e10), l11 = LIDX(e11);
+            Fp<P> x00, x01, x10, x11;
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                x00.v[l] = lds[l * row + l00]; x01.v[l] = lds[l * row + l01];
+                x10.v[l] = lds[l * row + l10]; x11.v[l] = lds[l * row + l11];
+            }
+            // stage s: (x00, x10) and (x01, x11)
+            Fp<P> a0 = fp_add<P>(x00, x10);
+            Fp<P> a1 = fp_mul<P>(load_fr<P>(tw_hi + (size_t)j0 * W), fp_sub_lazy<P>(x00, x10));
+            Fp<P> b0 = fp_add<P>(x01, x11);
+            Fp<P> b1 = fp_mul<P>(load_fr<P>(tw_hi + (size_t)j1 * W), fp_sub_lazy<P>(x01, x11));
+            // stage s-1: (a0, b0) and (a1, b1), one twiddle
+            const Fp<P> w2 = load_fr<P>(tw_lo + (size_t)j2 * W);
+            x00 = fp_add<P>(a0, b0);
+            x01 = fp_mul<P>(w2, fp_sub_lazy<P>(a0, b0));
+            x10 = fp_add<P>(a1, b1);
+            x11 = fp_mul<P>(w2, fp_sub_lazy<P>(a1, b1));
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                lds[l * row + l00] = x00.v[l]; lds[l * row + l01] = x01.v[l];
+                lds[l * row + l10] = x10.v[l]; lds[l * row + l11] = x11.v[l];
+            }
         }
         __syncthreads();
     }
