@@ -1232,7 +1232,8 @@ struct MsmPlan : MsmPlanBase {
                 const int cand = cands[k];
                 const uint64_t w = (FrP::BITS + 1 + cand - 1) / cand;
                 const int top_bits = FrP::BITS + 1 - (int)(w - 1) * cand;
-                if (n >= (1ull << 18) && w < 16 && (2 * top_bits >= cand || pre_c) && w * n <= (1ull << (31 - (cand - 13)))) { c = cand; break; }
+                // below 2^20 points the wider bucket set costs more in the (latency-bound) reduction than the windows save
+                if (n >= (1ull << 20) && w < 16 && (2 * top_bits >= cand || pre_c) && w * n <= (1ull << (31 - (cand - 13)))) { c = cand; break; }
                 if (pre_c) break;
             }
         }
