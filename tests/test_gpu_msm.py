@@ -304,6 +304,37 @@ def test_msm_skewed_scalars(gpu):
     _known_dl_case(gpu, n, N.ints_to_limbs(same), same)
 
 
+@pytest.mark.parametrize("flags", [0, 1])
+def test_msm_skewed_scalars_full_size(gpu, flags):
+    """2^20 pairs with degenerate scalar distributions, both plan modes (the fixed-base plan then runs 20-bit windows
+    on one shared bucket set): every scalar equal (one bucket per window holds all 2^20 entries: workgroup-tier combine,
+    unstaged level-B sort), all ones, and single-bit scalars 2^(i mod 254) like the benchmark circuit's witness"""
+    cid, grp, r = 0, 1, pyref.BN254.r
+    n = 1 << 20
+    k_limbs, k_ints = W.field_stream(W.SEED_MSM_BASES + 5, n, r)
+    gen = generator_limbs(gpu, cid, grp)
+    bases = np.zeros((n, 8), dtype=np.uint64)
+    N.check(gpu.zk_batch_mul(cid, grp, n, N.u64p(k_limbs), N.u64p(gen), 1, N.u64p(bases)))
+    ksum = sum(k_ints) % r
+    h = N._u64(0)
+    N.check(gpu.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, flags, 0, h))
+    try:
+        out, exp = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+        same = 0xDEADBEEFCAFEBABE1234567890ABCDEF0123456789ABCDEF
+        for value in (same, 1, r - 1):
+            sc = np.tile(N.ints_to_limbs([value]), (n, 1))
+            N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, 0, 0, N.u64p(out), None))
+            N.check(gpu.zk_point_mul(cid, grp, N.u64p(gen), N.u64p(N.ints_to_limbs([value * ksum % r])), N.u64p(exp)))
+            assert (out == exp).all(), hex(value)
+        limbs, ints = W.powers_of_two_scalars(n, r)
+        dot = sum(a * b for a, b in zip(ints, k_ints)) % r
+        N.check(gpu.zk_msm_plan_run(h, n, limbs.ctypes.data, 0, 0, 0, N.u64p(out), None))
+        N.check(gpu.zk_point_mul(cid, grp, N.u64p(gen), N.u64p(N.ints_to_limbs([dot])), N.u64p(exp)))
+        assert (out == exp).all()
+    finally:
+        N.check(gpu.zk_msm_plan_destroy(h))
+
+
 @pytest.mark.parametrize("n", [12345, 70001, (1 << 18) + 3, (1 << 19) + 1])
 def test_msm_odd_sizes_and_window_ranges(gpu, n):
     """sizes that are not powers of two (ragged last chunk / segment), as one run and as the three window ranges of a
@@ -339,6 +370,46 @@ def test_msm_odd_sizes_and_window_ranges(gpu, n):
     N.check(gpu.zk_msm_plan_run(h, m, sc_limbs.ctypes.data, 0, 0, 0, N.u64p(out), None))
     assert (out == exp).all()
     N.check(gpu.zk_msm_plan_destroy(h))
+
+
+def test_fixed_base_plan_ragged_size_above_2_20(gpu):
+    """(2^20 + 77) points: wide windows with a ragged last chunk / tile, a shorter scalar vector against the same plan and
+    a clone of the plan (shared table, own workspace) running concurrently"""
+    cid, grp, r = 0, 1, pyref.BN254.r
+    n = (1 << 20) + 77
+    sc_limbs, sc_ints = W.field_stream(0xF00D, n, r)
+    k_limbs, k_ints = W.field_stream(0xBEEF, n, r)
+    gen = generator_limbs(gpu, cid, grp)
+    bases = np.zeros((n, 8), dtype=np.uint64)
+    N.check(gpu.zk_batch_mul(cid, grp, n, N.u64p(k_limbs), N.u64p(gen), 1, N.u64p(bases)))
+
+    def expect(m):
+        e = np.zeros(8, dtype=np.uint64)
+        dot = sum(a * b for a, b in zip(sc_ints[:m], k_ints[:m])) % r
+        N.check(gpu.zk_point_mul(cid, grp, N.u64p(gen), N.u64p(N.ints_to_limbs([dot])), N.u64p(e)))
+        return e
+
+    h, h2 = N._u64(0), N._u64(0)
+    N.check(gpu.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, N.MSM_PRECOMPUTE, 0, h))
+    N.check(gpu.zk_msm_plan_clone(h, h2))
+    try:
+        cb, nw = N._i(0), N._i(0)
+        N.check(gpu.zk_msm_plan_windows(h, cb, nw))
+        assert cb.value == 20 and nw.value == 13          # the wide-window layout is what this test is about
+        a, b = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+        N.check(gpu.zk_msm_plan_enqueue(h, n, sc_limbs.ctypes.data, 0, 0, 0, N.STREAM_PLAN))
+        N.check(gpu.zk_msm_plan_enqueue(h2, n - 1000, sc_limbs.ctypes.data, 0, 0, 0, N.STREAM_PLAN))
+        N.check(gpu.zk_msm_plan_finish(h, N.u64p(a)))
+        N.check(gpu.zk_msm_plan_finish(h2, N.u64p(b)))
+        assert (a == expect(n)).all() and (b == expect(n - 1000)).all()
+        N.check(gpu.zk_msm_plan_destroy(h))               # the clone keeps the shared table alive
+        h = None
+        N.check(gpu.zk_msm_plan_run(h2, n, sc_limbs.ctypes.data, 0, 0, 0, N.u64p(b), None))
+        assert (b == a).all()
+    finally:
+        if h is not None:
+            N.check(gpu.zk_msm_plan_destroy(h))
+        N.check(gpu.zk_msm_plan_destroy(h2))
 
 
 def test_one_level_sort_path_still_correct(gpu):
