@@ -95,6 +95,8 @@ int zk_vec_op_dev(int curve, int op, uint64_t n, const void* d_a, const void* d_
 /* reduce every element below the modulus in place (Fr::from(BigUint), src/bn254/curve.rs:358-361): limb-array
  * witnesses handed to the device-resident provers are only ASSUMED canonical by the kernels behind them. */
 int zk_vec_canon_dev(int curve, uint64_t n, void* d_x, void* stream);
+/* d_out[k] = g^k for k < n, canonical (the powers of tau of a setup, python/zksnake/groth16/protocol.py:48-55) */
+int zk_vec_powers_dev(int curve, uint64_t n, const uint64_t* g, void* d_out, void* stream);
 
 /* SparseArray.dot (python/zksnake/array.py:36-44) as a CSR product over Fr on device-resident arrays:
  * row_ptr u32[n_rows + 1], cols u32[nnz], vals canonical Fr[nnz], w canonical Fr[n_cols] (cols must be < n_cols: the

@@ -257,8 +257,12 @@ def _sharded_prove_worker(rank, world, port, curve, log_n, q, backend="gloo"):
             assert (total == _points_to_limbs([E.G1() * sum(r + 5 for r in range(world))], E.curve.curve_id, 1)[0]).all()
         g = Groth16(R1CS.from_triplets(A, B, C, n, n_col, 2, curve), curve)
         g._toxic, g._blinding = TOXIC, BLIND
-        g.setup()
-        g.shard_over_ranks(dev)
+        if rank % 2 == 0:
+            g.shard_over_ranks(dev)   # before setup(): setup prepares this rank's window range only
+            g.setup()
+        else:
+            g.setup()                 # after: the full-range plans prepared by setup are dropped and rebuilt by range
+            g.shard_over_ranks(dev)
         proof = g.prove(N.ints_to_limbs(w[:2]), N.ints_to_limbs(w[2:]))
         g._blinding = None  # drawn on rank 0 and broadcast: all ranks still agree
         proof_r = g.prove(w[:2], w[2:])

@@ -64,6 +64,7 @@ SIGNATURES = {
     "zk_ntt_dev": (_i, [_i, _i, _i, _vp, _vp]),
     "zk_vec_op_dev": (_i, [_i, _i, _u64, _vp, _vp, _vp, _vp]),
     "zk_vec_canon_dev": (_i, [_i, _u64, _vp, _vp]),
+    "zk_vec_powers_dev": (_i, [_i, _u64, _u64p, _vp, _vp]),
     "zk_qap_h_dev": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_i), _vp]),
     "zk_msm": (_i, [_i, _i, _u64, _u64, _u64p, _u64p, _u64p]),
     "zk_batch_mul": (_i, [_i, _i, _u64, _u64p, _u64p, _i, _u64p]),
@@ -151,7 +152,17 @@ def ensure_gpu(device=None):
             device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, lib.zk_device_count())
         check(lib.zk_init(device))
         _initialised = True
+        global _device
+        _device = device
     return lib
+
+
+_device = 0
+
+
+def bind_thread():
+    """HIP's current device is per host thread: a worker thread calls this before its first library call"""
+    check(load().zk_init(_device))
 
 
 def u64p(arr):

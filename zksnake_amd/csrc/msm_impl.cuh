@@ -900,8 +900,17 @@ __global__ __launch_bounds__(COMBINE_THREADS) void combine_kernel(const uint32_t
         // every bucket, so an empty one is set to infinity here
         if (s1 - s0 == 1 || s1 - s0 > COMBINE_SMALL_MAX) return;
         HalfPt<F> acc = half_inf<F>();
-        if (s1 > s0) acc = half_load<F>(partials + (size_t)s0 * XW, odd);
-        for (uint32_t r = s0 + 1; r < s1; ++r) acc = pair_add<F>(acc, half_load<F>(partials + (size_t)r * XW, odd), odd);
+        if (s1 > s0) {
+            acc = half_load<F>(partials + (size_t)s0 * XW, odd);
+            // the next run is loaded before the addition of the current one: the chain is additions only, not
+            // load-then-add round trips
+            HalfPt<F> cur = s0 + 1 < s1 ? half_load<F>(partials + (size_t)(s0 + 1) * XW, odd) : half_inf<F>();
+            for (uint32_t r = s0 + 1; r < s1; ++r) {
+                HalfPt<F> nxt = r + 1 < s1 ? half_load<F>(partials + (size_t)(r + 1) * XW, odd) : half_inf<F>();
+                acc = pair_add<F>(acc, cur, odd);
+                cur = nxt;
+            }
+        }
         half_store<F>(buckets + (size_t)key * XW, odd, acc);
     } else if (blockIdx.x < small_blocks + COMBINE_WAVE_BLOCKS) {
         const uint32_t count = big_count[0];

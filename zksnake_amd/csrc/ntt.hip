@@ -46,6 +46,20 @@ __global__ void twiddle_kernel(uint32_t* out, Fp<P> zeta, uint32_t count) {
     store_fr<P>(out + (size_t)k * P::W, r);
 }
 
+// out[k] = g^k as canonical integers (setup: the powers of tau), square-and-multiply per element
+template <class P>
+__global__ void powers_kernel(uint32_t* out, Fp<P> g, uint32_t count) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    uint32_t e[1] = {k};
+    Fp<P> r = fp_pow<P>(g, e, 1);
+    uint32_t w[P::W];
+    fp_to_canonical<P>(w, r);
+    uint4* q = reinterpret_cast<uint4*>(out + (size_t)k * P::W);
+#pragma unroll
+    for (int i = 0; i < P::W / 4; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
 // ---- butterfly passes -----------------------------------------------------------------------
 // Decimation in frequency with the digit reversal folded into the passes.  Before a pass, `done` low bits of the
 // physical index hold finished (bit-reversed) frequency digits and the upper rem = log_n - done bits the remaining
@@ -771,6 +785,21 @@ int zk_spmv_long_dev(int curve, uint64_t n_long, const void* d_long_rows, const 
                            (uint32_t*)d_out);                                                                            \
         ZK_HIP(hipGetLastError());                                                                                       \
         return ZK_OK;                                                                                                    \
+    }
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_vec_powers_dev(int curve, uint64_t n, const uint64_t* g, void* d_out, void* stream) {
+    if (n == 0) return ZK_OK;
+    if (n > (1ull << 32)) return fail(ZK_ERR_ARG, "too many powers");
+#define CALL(P)                                                                                                        \
+    {                                                                                                                  \
+        Fp<P> gm = fp_from_canonical<P>(reinterpret_cast<const uint32_t*>(g));                                         \
+        hipLaunchKernelGGL(powers_kernel<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,     \
+                           (uint32_t*)d_out, gm, (uint32_t)n);                                                         \
+        ZK_HIP(hipGetLastError());                                                                                     \
+        return ZK_OK;                                                                                                  \
     }
     ZK_DISPATCH_FR(curve, CALL);
 #undef CALL

@@ -189,6 +189,12 @@ class FrOps:
             vec.upload(limbs)
         return vec
 
+    def d_powers(self, g, count):
+        """DevVec of (1, g, g^2, ..), computed on the device"""
+        vec = DevVec(count, zero=False)
+        N.check(N.load().zk_vec_powers_dev(self.cid, count, N.u64p(self.one(g)), vec.ptr(), None))
+        return vec
+
     def d_ntt(self, vec, size, inverse=False):
         """in place on the first `size` (a power of two) elements"""
         assert size & (size - 1) == 0 and size <= vec.n

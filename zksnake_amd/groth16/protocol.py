@@ -53,8 +53,11 @@ class Groth16:
         self._shard = None      # (rank, world, torch device or None) once shard_over_ranks() was called
 
     # ------------------------------------------------------------------------------------------
-    def setup(self):
-        """trusted setup: ProvingKey and VerifyingKey from fresh (or pinned) toxic waste"""
+    def setup(self, prepare_prover=True):
+        """trusted setup: ProvingKey and VerifyingKey from fresh (or pinned) toxic waste.
+        prepare_prover (not in the reference's signature): also build what the first prove() would otherwise build -- the
+        device-resident fixed-base plans of the four key vectors and the CSR matrices -- on a worker thread, beside the
+        host-side matrix work of the setup, so that the first proof costs what every later one does."""
         q = self.order
         G1, G2 = self.E.G1(), self.E.G2()
         if self._toxic is not None:
@@ -73,11 +76,24 @@ class Groth16:
         # L = A^T lag, R = B^T lag, O = C^T lag (transposed CSR SpMV), K = beta L + alpha R + O
         # L_i(tau) = (1/n) sum_j tau^j w^(-ij): the inverse transform of the powers of tau (one 0.2 ms iNTT instead of
         # n sequential host products and an inversion, evaluate_lagrange_coefficients of polynomial.rs:645-652)
-        powers = V.powers(tau, n)
-        d_pow = V.d_from(powers)
+        d_pow = V.d_powers(tau, n)
+        powers = d_pow.download()
         d_lag = DevVec(n, zero=False)
         V.d_copy(n, d_pow.ptr(), d_lag.ptr())
         V.d_ntt(d_lag, n, inverse=True)
+
+        # the key vectors that depend on the toxic waste only come first: their fixed-base plans are then built on a worker
+        # thread (GPU: chains of doublings; the calls release the GIL) while this thread transposes the matrices (numpy)
+        t = mod.evaluate_vanishing_polynomial(n, tau)
+        d_shift = DevVec(n, zero=False)
+        N.check(lib.zk_vec_axpby_dev(cid, n, N.u64p(V.one(t * inv_delta % q)), d_pow.ptr(), None, None, None, d_shift.ptr(), None))
+        shifted = d_shift.download()
+        tau_G1 = self.E.batch_mul(G1, powers, as_array=True)
+        tau_G2 = self.E.batch_mul(G2, powers, as_array=True)
+        target_G1 = self.E.batch_mul(G1, shifted, as_array=True)
+        worker = self._start_plan_worker([(tau_G1, 1, 0, False), (tau_G2, 2, 0, True), (tau_G1, 1, 1, False), (target_G1, 1, 0, False)]) \
+            if prepare_prover else None
+
         sums = []
         for mat in (self.qap.a, self.qap.b, self.qap.c):
             out = DevVec(n_wires)
@@ -95,16 +111,17 @@ class Groth16:
         if n_wires > n_pub:
             N.check(lib.zk_vec_axpby_dev(cid, n_wires - n_pub, N.u64p(V.one(inv_delta)), K.ptr(n_pub), None, None, None, k_delta.ptr(), None))
 
-        # powers of tau and their t(tau)/delta multiples
-        t = mod.evaluate_vanishing_polynomial(n, tau)
-        N.check(lib.zk_vec_axpby_dev(cid, n, N.u64p(V.one(t * inv_delta % q)), d_pow.ptr(), None, None, None, d_pow.ptr(), None))
-        shifted = d_pow.download()
-
-        tau_G1 = self.E.batch_mul(G1, powers, as_array=True)
-        tau_G2 = self.E.batch_mul(G2, powers, as_array=True)
-        target_G1 = self.E.batch_mul(G1, shifted, as_array=True)
         k_gamma_G1 = self.E.batch_mul(G1, k_gamma.download(n_pub), as_array=True) if n_pub else []
         k_delta_G1 = self.E.batch_mul(G1, k_delta.download(n_wires - n_pub), as_array=True) if n_wires > n_pub else []
+        if worker is not None:
+            worker.join()
+            if worker.error is not None:
+                raise worker.error
+            if n_wires > n_pub:
+                self._build_plan(k_delta_G1, 1, 0, False)
+            self.qap._device_matrices()
+            self.qap._workspace(n, n_wires)
+            self.qap._qap_stream()
 
         alpha_G1, beta_G1, delta_G1 = G1 * alpha, G1 * beta, G1 * delta
         beta_G2, gamma_G2, delta_G2 = G2 * beta, G2 * gamma, G2 * delta
@@ -112,12 +129,52 @@ class Groth16:
         self.verifying_key = VerifyingKey(alpha_G1, beta_G2, gamma_G2, delta_G2, k_gamma_G1)
 
     # ------------------------------------------------------------------------------------------
+    def _plan_range(self, arr):
+        """(first, count) of this rank's windows for an MSM over `arr`, or None without sharding"""
+        if self._shard is None or self._shard[1] <= 1:
+            return None
+        from ..parallel import window_ranges
+        c, nwin = N.ctypes.c_int(0), N.ctypes.c_int(0)
+        N.check(N.load().zk_msm_window_layout(self.E.curve.curve_id, len(arr), 0, c, nwin))
+        return window_ranges(nwin.value, self._shard[1])[self._shard[0]]
+
+    def _build_plan(self, arr, group, slot, high_priority):
+        rng = self._plan_range(arr)
+        if rng is not None:
+            if rng[1] == 0:
+                return None
+            arr.window_range = rng
+        return arr.plan(slot, precompute=self.precompute_keys, high_priority=high_priority)
+
+    def _start_plan_worker(self, jobs):
+        import threading
+
+        def run():
+            try:
+                N.bind_thread()
+                for arr, group, slot, hp in jobs:
+                    self._build_plan(arr, group, slot, hp)
+            except Exception as exc:  # noqa: BLE001 - re-raised by the caller after join()
+                worker.error = exc
+
+        worker = threading.Thread(target=run, name="zkmi-plan-builder")
+        worker.error = None
+        worker.start()
+        return worker
+
     def shard_over_ranks(self, device=None):
         """split the windows of every MSM in prove() over the ranks of the default torch.distributed group
         (one process per GPU; backend nccl = RCCL, or gloo).  `device` is where the gathered partial points
-        are staged (the rank's GPU for RCCL, None for gloo)."""
+        are staged (the rank's GPU for RCCL, None for gloo).  Call it BEFORE setup() so that the plans built there cover
+        this rank's windows only; plans that already exist for all windows are dropped and rebuilt by range on the next
+        prove()."""
         import torch.distributed as dist
         self._shard = (dist.get_rank(), dist.get_world_size(), device)
+        if self._shard[1] > 1 and self.proving_key is not None:
+            pk = self.proving_key
+            for arr in (pk.tau_1, pk.tau_2, pk.target_1, pk.kdelta_1):
+                if isinstance(arr, PointArray) and arr.window_range is None:
+                    arr.release()
 
     def _enqueue_msm(self, bases, group, d_scalars, count, slot=0, high_priority=False):
         """start <bases[:count], scalars> (scalars already in HBM) on the plan's own stream; with sharding only
@@ -125,13 +182,11 @@ class Groth16:
         lib = N.load()
         arr = _as_array(self.E, bases, group)
         first, cnt = 0, 0  # 0, 0 = all windows
-        if self._shard is not None and self._shard[1] > 1:
+        rng = self._plan_range(arr)
+        if rng is not None:
             # this rank's windows are known before the plan exists, so the plan (fixed-base table rows, workspace) is
             # created for that range only: 1/8 of the table memory and build time on 8 ranks
-            from ..parallel import window_ranges
-            c, nwin = N.ctypes.c_int(0), N.ctypes.c_int(0)
-            N.check(lib.zk_msm_window_layout(self.E.curve.curve_id, len(arr), 0, c, nwin))
-            first, cnt = window_ranges(nwin.value, self._shard[1])[self._shard[0]]
+            first, cnt = rng
             if cnt == 0:
                 return arr, None
             arr.window_range = (first, cnt)
