@@ -168,6 +168,10 @@ int zk_msm_plan_run(uint64_t handle, uint64_t n_scalars, const void* scalars, in
 #define ZK_STREAM_PLAN ((void*)(intptr_t)-1)
 int zk_msm_plan_enqueue(uint64_t handle, uint64_t n_scalars, const void* scalars, int scalars_on_device,
                         int window_first, int window_count, void* stream);
+/* The same scalars against a second set of bases (Groth16: <tau_1, v> in G1 and <tau_2, v> in G2): run `handle` on the
+ * digits and the sorted entry list of `lender_handle`'s run in flight instead of sorting again.  Both plans must have the
+ * same size, window layout, mode and window range (else ZK_ERR_ARG: enqueue normally); finish both as usual. */
+int zk_msm_plan_enqueue_shared(uint64_t handle, uint64_t lender_handle, void* stream);
 int zk_msm_plan_finish(uint64_t handle, uint64_t* out);
 int zk_msm_plan_windows(uint64_t handle, int* window_bits, int* n_windows);
 /* the window width and count a plan over n points will use (window_bits 0 = automatic), without creating one: what a

@@ -412,6 +412,48 @@ def test_fixed_base_plan_ragged_size_above_2_20(gpu):
         N.check(gpu.zk_msm_plan_destroy(h2))
 
 
+@pytest.mark.parametrize("flags,n", [(1, 5000), (0, 5000), (1, 1 << 20)])
+def test_shared_sort_between_g1_and_g2_plans(gpu, flags, n):
+    """zk_msm_plan_enqueue_shared: the G2 plan runs on the digits and the sorted entry list of the G1 plan's run in flight
+    (Groth16's <tau_1, v> and <tau_2, v>); results equal the independently sorted runs, the lender can run again at once,
+    and plans of different sizes refuse to share"""
+    cid, r = 0, pyref.BN254.r
+    sc = W.field_stream(0x5A5A, n, r)[0]
+    sc2 = W.field_stream(0xA5A5, n, r)[0]
+    plans, singles = {}, {}
+    for grp in (1, 2):
+        bases, _ = _bases_from_library(gpu, cid, grp, n, 0xC0FFEE + grp)
+        h = N._u64(0)
+        N.check(gpu.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, flags, 0, h))
+        plans[grp] = h
+        for tag, s_ in (("a", sc), ("b", sc2)):
+            out = np.zeros(N.point_limbs(cid, grp), dtype=np.uint64)
+            N.check(gpu.zk_msm_plan_run(h, n, s_.ctypes.data, 0, 0, 0, N.u64p(out), None))
+            singles[(grp, tag)] = out
+    try:
+        for tag, s_ in (("a", sc), ("b", sc2), ("a", sc)):   # back to back: the lender's buffers are reused while lent
+            o1, o2 = np.zeros(8, dtype=np.uint64), np.zeros(16, dtype=np.uint64)
+            N.check(gpu.zk_msm_plan_enqueue(plans[1], n, s_.ctypes.data, 0, 0, 0, N.STREAM_PLAN))
+            N.check(gpu.zk_msm_plan_enqueue_shared(plans[2], plans[1], N.STREAM_PLAN))
+            N.check(gpu.zk_msm_plan_finish(plans[1], N.u64p(o1)))
+            N.check(gpu.zk_msm_plan_finish(plans[2], N.u64p(o2)))
+            assert (o1 == singles[(1, tag)]).all() and (o2 == singles[(2, tag)]).all()
+        # nothing in flight on the lender -> refused; a plan of another size -> refused
+        assert gpu.zk_msm_plan_enqueue_shared(plans[2], plans[1], N.STREAM_PLAN) == N.ZK_ERR_ARG
+        small_bases, _ = _bases_from_library(gpu, cid, 2, 64, 0xC0FFEE)
+        hs = N._u64(0)
+        N.check(gpu.zk_msm_plan_create(cid, 2, 64, small_bases.ctypes.data, 0, flags, 0, hs))
+        N.check(gpu.zk_msm_plan_enqueue(plans[1], n, sc.ctypes.data, 0, 0, 0, N.STREAM_PLAN))
+        assert gpu.zk_msm_plan_enqueue_shared(hs, plans[1], N.STREAM_PLAN) == N.ZK_ERR_ARG
+        o1 = np.zeros(8, dtype=np.uint64)
+        N.check(gpu.zk_msm_plan_finish(plans[1], N.u64p(o1)))
+        assert (o1 == singles[(1, "a")]).all()
+        N.check(gpu.zk_msm_plan_destroy(hs))
+    finally:
+        for h in plans.values():
+            N.check(gpu.zk_msm_plan_destroy(h))
+
+
 def test_one_level_sort_path_still_correct(gpu):
     """the chunked one-level sort now only serves n > 2^24 (and the ZKMI_NO_TWO_LEVEL knob): keep it checked, in a child
     process because the knob is read once per process"""

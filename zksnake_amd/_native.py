@@ -74,6 +74,7 @@ SIGNATURES = {
     "zk_msm_plan_destroy": (_i, [_u64]),
     "zk_msm_plan_run": (_i, [_u64, _u64, _vp, _i, _i, _i, _u64p, _vp]),
     "zk_msm_plan_enqueue": (_i, [_u64, _u64, _vp, _i, _i, _i, _vp]),
+    "zk_msm_plan_enqueue_shared": (_i, [_u64, _u64, _vp]),
     "zk_msm_plan_finish": (_i, [_u64, _u64p]),
     "zk_msm_plan_windows": (_i, [_u64, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "zk_msm_window_layout": (_i, [_i, _u64, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),

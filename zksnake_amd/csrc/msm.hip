@@ -100,6 +100,13 @@ int zk_msm_plan_enqueue(uint64_t handle, uint64_t n_scalars, const void* scalars
     return p->enqueue(n_scalars, scalars, scalars_on_device, window_first, window_count, pick_stream(p, stream));
 }
 
+int zk_msm_plan_enqueue_shared(uint64_t handle, uint64_t lender_handle, void* stream) {
+    MsmPlanBase* p = find_plan(handle);
+    MsmPlanBase* lender = find_plan(lender_handle);
+    if (!p || !lender || p == lender) return fail(ZK_ERR_ARG, "unknown MSM plan handle");
+    return p->enqueue_shared(lender, pick_stream(p, stream));
+}
+
 int zk_msm_plan_finish(uint64_t handle, uint64_t* out) {
     MsmPlanBase* p = find_plan(handle);
     if (!p) return fail(ZK_ERR_ARG, "unknown MSM plan handle");

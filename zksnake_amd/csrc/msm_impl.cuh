@@ -1189,6 +1189,9 @@ struct MsmPlan : MsmPlanBase {
         uint32_t *sorted = nullptr, *partials = nullptr, *buckets = nullptr, *rows = nullptr, *fin = nullptr;
         uint32_t *tmp_ref = nullptr, *bin_start = nullptr, *slice_sums = nullptr, *bin_tot = nullptr;  // two-level sort
         hipEvent_t ev_begin = nullptr, ev_acc0 = nullptr, ev_acc1 = nullptr, ev_done = nullptr;
+        hipEvent_t ev_release = nullptr;  // recorded by a borrower of this run's sort (enqueue_shared) after its last read
+        bool lent = false;
+        uint32_t seg_len = 0;
         int w_first = 0, w_count = 0;  // windows of the run in flight
         uint32_t groups = 0;           // bucket sets of the run in flight
     };
@@ -1214,7 +1217,7 @@ struct MsmPlan : MsmPlanBase {
                         d_scalars, d_dig};
         for (void* q : bufs) if (q) (void)hipFree(q);
         if (h_final) (void)hipHostFree(h_final);
-        for (hipEvent_t e : {ws.ev_begin, ws.ev_acc0, ws.ev_acc1, ws.ev_done, ev_start, ev_digits, ev_end}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ws.ev_begin, ws.ev_acc0, ws.ev_acc1, ws.ev_done, ws.ev_release, ev_start, ev_digits, ev_end}) if (e) (void)hipEventDestroy(e);
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
 
@@ -1339,7 +1342,7 @@ struct MsmPlan : MsmPlanBase {
             ZK_HIP(hipMalloc(&ws.buckets, keys * XW * 4));
             ZK_HIP(hipMalloc(&ws.rows, max_sets * (R + C) * XW * 4));
             ZK_HIP(hipMalloc(&ws.fin, max_sets * (bpr + bpc) * 2 * XW * 4));
-            for (hipEvent_t* e : {&ws.ev_begin, &ws.ev_acc0, &ws.ev_acc1, &ws.ev_done}) ZK_HIP(hipEventCreate(e));
+            for (hipEvent_t* e : {&ws.ev_begin, &ws.ev_acc0, &ws.ev_acc1, &ws.ev_done, &ws.ev_release}) ZK_HIP(hipEventCreate(e));
         }
         // LDS above 64 KiB needs the opt-in
         int lds_bytes = (int)((wide ? (1u << 15) : B) * 4);  // the one-level kernels never run for wide windows
@@ -1417,15 +1420,23 @@ struct MsmPlan : MsmPlanBase {
     }
 
     // stages 2..7 + D2H for the windows [ws.w_first, ws.w_first + ws.w_count) on stream st
-    int run_stages(uint32_t m, uint32_t dstride, hipStream_t st) {
+    // `borrowed`: the digits and the sort of another plan's run over the same scalars (enqueue_shared); stages 1-4 are skipped
+    int run_stages(uint32_t m, uint32_t dstride, hipStream_t st, const SortExport* borrowed = nullptr) {
         Work& l = ws;
         const int w_first = l.w_first, w_count = l.w_count;
         const uint32_t groups = l.groups;
         const uint32_t n_keys = groups * B;
         const int nchunk = chunks_for(w_count, m);  // this run's windows fill the chip
-        const uint32_t seg_len = pick_seg_len((uint64_t)w_count * m);
+        const uint32_t seg_len = borrowed ? borrowed->seg_len : pick_seg_len((uint64_t)w_count * m);
+        l.seg_len = seg_len;
         const uint32_t ch_len = (m + nchunk - 1) / nchunk;
         ZK_HIP(hipEventRecord(l.ev_begin, st));
+        const uint32_t *p_sorted = l.sorted, *p_bstart = l.bstart, *p_sstart = l.sstart, *p_big_list = l.big_list, *p_big_count = l.big_count;
+        if (borrowed) {
+            p_sorted = borrowed->sorted; p_bstart = borrowed->bstart; p_sstart = borrowed->sstart;
+            p_big_list = borrowed->big_list; p_big_count = borrowed->big_count;
+            ZK_HIP(hipStreamWaitEvent(st, borrowed->sorted_ready, 0));
+        } else {
         // digit rows are stored relative to the plan's first window; the kernels index them with absolute windows
         const uintptr_t dig_base = reinterpret_cast<uintptr_t>(this->d_dig) - (uintptr_t)pw_first * dstride * (wide ? 4 : 2);
         const uint16_t* d_dig = reinterpret_cast<const uint16_t*>(dig_base);
@@ -1483,15 +1494,17 @@ struct MsmPlan : MsmPlanBase {
             const unsigned blocks = pre ? (unsigned)(w_count * nchunk) : (unsigned)(8 * ((w_count + 7) / 8) * nchunk);
             hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(SORT_THREADS), B * 4, st, d_dig, m, dstride, c, w_first, w_count, nchunk, ch_len, pre ? 1 : 0, (uint32_t)n, pw_first, l.hist, l.bstart, l.sorted);
         }
+        }  // !borrowed
         ZK_HIP(hipEventRecord(l.ev_acc0, st));
         // 5. accumulate
         uint64_t lanes_needed = ((uint64_t)w_count * m + seg_len - 1) / seg_len;
-        hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((lanes_needed + 255) / 256)), dim3(256), 0, st, d_bases, l.sorted, l.bstart, l.sstart, n_keys, seg_len, l.partials, l.buckets);
+        hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((lanes_needed + 255) / 256)), dim3(256), 0, st, d_bases, p_sorted, p_bstart, p_sstart, n_keys, seg_len, l.partials, l.buckets);
         ZK_HIP(hipEventRecord(l.ev_acc1, st));
         // 6. combine (three tiers, one launch)
         const uint32_t small_blocks = (2 * n_keys + COMBINE_THREADS - 1) / COMBINE_THREADS;
         hipLaunchKernelGGL(combine_kernel<G>, dim3(small_blocks + COMBINE_WAVE_BLOCKS + COMBINE_BIG_BLOCKS), dim3(COMBINE_THREADS), 0, st,
-                           l.partials, l.sstart, n_keys, small_blocks, l.big_list, l.big_count, l.buckets);
+                           l.partials, p_sstart, n_keys, small_blocks, p_big_list, p_big_count, l.buckets);
+        if (borrowed) ZK_HIP(hipEventRecord(borrowed->release, st));  // the lender's buffers are no longer read
         // 7. reduce: rows (sum over lo), cols (sum over hi), weighted sums
         uint32_t n_rows = groups * R, n_cols = groups * C;
         SumJob rows = {n_rows, R, B, C, 1u, C, 0u};
@@ -1537,6 +1550,10 @@ struct MsmPlan : MsmPlanBase {
                                         std::to_string(pw_first + pw_count) + "))");
         const uint32_t m = (uint32_t)n_scalars;
         q_first = w_first; q_count = w_count; q_m = m; q_stream = st;
+        if (ws.lent) {  // a borrower of the previous run's sort may still be reading the buffers this run overwrites
+            ZK_HIP(hipStreamWaitEvent(st, ws.ev_release, 0));
+            ws.lent = false;
+        }
         if (m > 0) {
             const uint32_t* sc = (const uint32_t*)scalars;
             if (!on_device) {
@@ -1565,6 +1582,49 @@ struct MsmPlan : MsmPlanBase {
             if (rc) return rc;
             ZK_HIP(hipEventRecord(ev_end, st));
         }
+        q_pending = true;
+        return ZK_OK;
+    }
+
+    int export_sort(SortExport* out) override {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!q_pending || q_m == 0) return fail(ZK_ERR_ARG, "the lending plan has no run in flight");
+        out->sorted = ws.sorted; out->bstart = ws.bstart; out->sstart = ws.sstart;
+        out->big_list = ws.big_list; out->big_count = ws.big_count;
+        out->n = n; out->m = q_m; out->seg_len = ws.seg_len; out->groups = ws.groups;
+        out->c = c; out->nwin = nwin; out->w_first = q_first; out->w_count = q_count;
+        out->pw_first = pw_first; out->pw_count = pw_count; out->scalar_bits = FrP::BITS; out->pre = pre;
+        out->sorted_ready = ws.ev_acc0;
+        out->release = ws.ev_release;
+        ws.lent = true;
+        return ZK_OK;
+    }
+
+    // Run this plan on the digits and the sorted entry list of `lender`'s run in flight: same scalars, other bases
+    // (Groth16's <tau_1, v> and <tau_2, v>).  Both plans must have the same size, window layout, mode and window range;
+    // the entry list addresses points (or table rows) by index, which is independent of the group.
+    int enqueue_shared(MsmPlanBase* lender, hipStream_t st) override {
+        SortExport ex;
+        int rc = lender->export_sort(&ex);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> lock(mu);
+        if (q_pending) return fail(ZK_ERR_ARG, "MSM plan already has a run in flight: call zk_msm_plan_finish first");
+        if (ex.n != n || ex.c != c || ex.nwin != nwin || ex.pre != pre || ex.scalar_bits != FrP::BITS || ex.pw_first != pw_first ||
+            ex.pw_count != pw_count)
+            return fail(ZK_ERR_ARG, "plans differ in size, window layout or mode: the sort cannot be shared");
+        if (ws.lent) {
+            ZK_HIP(hipStreamWaitEvent(st, ws.ev_release, 0));
+            ws.lent = false;
+        }
+        q_first = ex.w_first; q_count = ex.w_count; q_m = ex.m; q_stream = st;
+        ZK_HIP(hipEventRecord(ev_start, st));
+        ZK_HIP(hipEventRecord(ev_digits, st));
+        ws.w_first = ex.w_first;
+        ws.w_count = ex.w_count;
+        ws.groups = ex.groups;
+        rc = run_stages(ex.m, (ex.m + 7u) & ~7u, st, &ex);
+        if (rc) return rc;
+        ZK_HIP(hipEventRecord(ev_end, st));
         q_pending = true;
         return ZK_OK;
     }

@@ -15,8 +15,22 @@ struct DeviceBlock {
     }
 };
 
+// what a plan with a run in flight lends to a second plan that multiplies the SAME scalars against other bases of the
+// same length (Groth16: <tau_1, v> in G1 and <tau_2, v> in G2): the digits and the sorted entry list
+struct SortExport {
+    const uint32_t *sorted = nullptr, *bstart = nullptr, *sstart = nullptr, *big_list = nullptr, *big_count = nullptr;
+    uint64_t n = 0;
+    uint32_t m = 0, seg_len = 0, groups = 0;
+    int c = 0, nwin = 0, w_first = 0, w_count = 0, pw_first = 0, pw_count = 0, scalar_bits = 0;
+    bool pre = false;
+    hipEvent_t sorted_ready = nullptr;  // recorded on the lender's stream after its sort stage
+    hipEvent_t release = nullptr;       // the borrower records it after its last read; the lender's next run waits for it
+};
+
 struct MsmPlanBase {
     virtual ~MsmPlanBase() {}
+    virtual int export_sort(SortExport* out) = 0;                        // of the run in flight
+    virtual int enqueue_shared(MsmPlanBase* lender, hipStream_t stream) = 0;
     // a second plan over the same bases (shared, read-only) with its own workspace and stream: two MSMs against one key
     // in flight together (tau_1 with u and with v in Groth16.prove) without building the fixed-base table twice
     virtual int clone(MsmPlanBase** out) = 0;

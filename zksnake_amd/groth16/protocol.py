@@ -15,6 +15,8 @@ Multi-GPU (BASELINE config 5): after `shard_over_ranks()` every ra
 ranks travel in one all_gather (RCCL) and every rank assembles the same proof.
 """
 
+import os
+
 import numpy as np
 
 from .. import _native as N
@@ -176,7 +178,7 @@ class Groth16:
                 if isinstance(arr, PointArray) and arr.window_range is None:
                     arr.release()
 
-    def _enqueue_msm(self, bases, group, d_scalars, count, slot=0, high_priority=False):
+    def _enqueue_msm(self, bases, group, d_scalars, count, slot=0, high_priority=False, share_sort_of=None):
         """start <bases[:count], scalars> (scalars already in HBM) on the plan's own stream; with sharding only
         this rank's windows.  Returns (array, handle); handle None = this rank has no window of that MSM."""
         lib = N.load()
@@ -191,6 +193,10 @@ class Groth16:
                 return arr, None
             arr.window_range = (first, cnt)
         handle = arr.plan(slot, precompute=self.precompute_keys, high_priority=high_priority)
+        if share_sort_of is not None and count == len(arr) and not os.environ.get("ZKMI_NO_SHARED_SORT"):
+            # <tau_1, v> is already in flight with the same scalars: B2 = <tau_2, v> reuses its digits and sorted entries
+            if lib.zk_msm_plan_enqueue_shared(handle, share_sort_of, N.STREAM_PLAN) == N.ZK_OK:
+                return arr, handle
         N.check(lib.zk_msm_plan_enqueue(handle, count, d_scalars, 1, first, cnt, N.STREAM_PLAN))
         return arr, handle
 
@@ -264,9 +270,9 @@ class Groth16:
         # the four MSMs over u, v, h are put in flight on their plans' own streams, then collected: the latency-bound
         # bucket reductions of one overlap with the accumulation kernels of the others.  The G2 MSM (three times the
         # work of a G1 one, and the longest reduction tail) goes first, on a high-priority stream.
-        pk.tau_2, h_v2 = self._enqueue_msm(pk.tau_2, 2, res.v.ptr, min(n, len(pk.tau_2)), high_priority=True)
-        pk.tau_1, h_u = self._enqueue_msm(pk.tau_1, 1, res.u.ptr, min(n, len(pk.tau_1)), slot=0)
         pk.tau_1, h_v1 = self._enqueue_msm(pk.tau_1, 1, res.v.ptr, min(n, len(pk.tau_1)), slot=1)
+        pk.tau_2, h_v2 = self._enqueue_msm(pk.tau_2, 2, res.v.ptr, min(n, len(pk.tau_2)), high_priority=True, share_sort_of=h_v1)
+        pk.tau_1, h_u = self._enqueue_msm(pk.tau_1, 1, res.u.ptr, min(n, len(pk.tau_1)), slot=0)
         pk.target_1, h_h = self._enqueue_msm(pk.target_1, 1, res.h.ptr, min(n, len(pk.target_1)))
         h_k = early.get("k")
         t_enq = time.perf_counter()
