@@ -145,8 +145,9 @@ __device__ __forceinline__ void xyzz_add_affine_mem(XYZZ<F>& acc, const uint32_t
         T U2, S2;
         {
             Affine<F> q = load_affine_row<F>(src);
-            if (aff_is_inf<F>(q)) return;
-            if (xyzz_is_inf<F>(acc)) {
+            // the sentinel and an empty accumulator are exact zeros (written as such), so the limb test is enough here
+            if (F::is_zero_limbs(q.x) && F::is_zero_limbs(q.y)) return;
+            if (F::is_zero_limbs(acc.ZZ)) {
                 acc = {q.x, negate ? F::neg(q.y) : q.y, F::one(), F::one()};
                 return;
             }
@@ -181,9 +182,10 @@ __device__ __forceinline__ void xyzz_add_affine_mem(XYZZ<F>& acc, const uint32_t
         T U2, S2;
         {
             Affine<F> q = load_affine_row<F>(src);
-            if (aff_is_inf<F>(q)) return;
+            // the sentinel and an empty accumulator are exact zeros (written as such), so the limb test is enough here
+            if (F::is_zero_limbs(q.x) && F::is_zero_limbs(q.y)) return;
             if (negate) q.y = F::neg(q.y);
-            if (xyzz_is_inf<F>(acc)) {
+            if (F::is_zero_limbs(acc.ZZ)) {
                 acc = {q.x, q.y, F::one(), F::one()};
                 return;
             }

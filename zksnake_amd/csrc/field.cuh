@@ -84,6 +84,16 @@ ZK_HD bool fp_is_zero(const Fp<P>& a) {
     return z == 0 || e == 0;
 }
 
+// all limbs zero: the exact representative 0 (not p).  Enough where zero only ever arises by assignment -- the (0, 0)
+// infinity sentinel of an affine row, the ZZ = 0 of an empty accumulator -- and a third of the instructions of fp_is_zero
+template <class P>
+ZK_HD bool fp_is_zero_limbs(const Fp<P>& a) {
+    uint32_t z = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) z |= a.v[i];
+    return z == 0;
+}
+
 // ---- addition / subtraction: both candidates (x and x -/+ 2p) are carried through one pass of signed
 // carries and the in-range one is selected, so the result is normalized and again in [0, 2p) ------------
 
@@ -550,6 +560,7 @@ struct FpOps {
     static ZK_HD T dbl(const T& a) { return fp_dbl<P>(a); }
     static ZK_HD T inv(const T& a) { return fp_inv<P>(a); }
     static ZK_HD bool is_zero(const T& a) { return fp_is_zero<P>(a); }
+    static ZK_HD bool is_zero_limbs(const T& a) { return fp_is_zero_limbs<P>(a); }
     static ZK_HD bool eq(const T& a, const T& b) { return fp_eq<P>(a, b); }
     static ZK_HD T from_canonical(const uint32_t* w) { return fp_from_canonical<P>(w); }
     static ZK_HD void to_canonical(uint32_t* w, const T& a) { fp_to_canonical<P>(w, a); }
@@ -591,6 +602,7 @@ struct Fp2Ops {
     static ZK_HD T dbl(const T& a) { return fp2_dbl<P>(a); }
     static ZK_HD T inv(const T& a) { return fp2_inv<P>(a); }
     static ZK_HD bool is_zero(const T& a) { return fp2_is_zero<P>(a); }
+    static ZK_HD bool is_zero_limbs(const T& a) { return fp_is_zero_limbs<P>(a.c0) && fp_is_zero_limbs<P>(a.c1); }
     static ZK_HD bool eq(const T& a, const T& b) { return fp2_eq<P>(a, b); }
     static ZK_HD T from_canonical(const uint32_t* w) {
         return {fp_from_canonical<P>(w), fp_from_canonical<P>(w + P::W)};
