@@ -7,6 +7,7 @@ point fails with ZkError (status ZK_ERR_HIP).
 """
 
 import ctypes
+import operator
 import os
 import threading
 
@@ -210,7 +211,7 @@ def ints_to_limbs(vals, words=4, modulus=None):
     nbytes = 8 * words
     chunks = []
     for v in vals:
-        v = int(v)
+        v = operator.index(v)  # ints and numpy integers; floats raise TypeError as pyo3's extraction does
         if v < 0:
             raise OverflowError("can't convert negative int to unsigned")
         if modulus is not None and v >= modulus:

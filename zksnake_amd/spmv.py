@@ -16,6 +16,24 @@ LONG_ROW = 64     # rows with more entries leave the lane-per-row kernel
 ITEM = 4096       # entries per work item of a long row
 
 
+def long_row_items(row_ptr, long_row=LONG_ROW, item=ITEM):
+    """(long_rows, item_ptr, items): the rows with more than `long_row` entries, and their entry ranges cut into work
+    items [k0, k1) of at most `item` entries; items[item_ptr[j]:item_ptr[j + 1]] belong to long_rows[j].  Pure numpy."""
+    rp = np.asarray(row_ptr).astype(np.int64)
+    lengths = np.diff(rp)
+    long_rows = np.nonzero(lengths > long_row)[0]
+    per_row = (lengths[long_rows] + item - 1) // item
+    item_ptr = np.zeros(long_rows.shape[0] + 1, dtype=np.uint32)
+    np.cumsum(per_row, out=item_ptr[1:])
+    n_items = int(item_ptr[-1])
+    row_of = np.repeat(np.arange(long_rows.shape[0]), per_row)
+    k_in_row = np.arange(n_items) - item_ptr[:-1].astype(np.int64)[row_of]
+    start = rp[long_rows][row_of] + k_in_row * item
+    end = np.minimum(start + item, rp[long_rows + 1][row_of])
+    items = np.stack([start, end], axis=1).astype(np.uint32).reshape(-1, 2)
+    return long_rows.astype(np.uint32), item_ptr, np.ascontiguousarray(items)
+
+
 class DeviceCsr:
     def __init__(self, curve_id, row_ptr, cols, vals):
         self.cid = curve_id
@@ -23,23 +41,13 @@ class DeviceCsr:
         self.row_ptr = DeviceBuffer.from_numpy(np.ascontiguousarray(row_ptr, dtype=np.uint32))
         self.cols = DeviceBuffer.from_numpy(np.ascontiguousarray(cols, dtype=np.uint32)) if len(cols) else None
         self.vals = DeviceBuffer.from_numpy(np.ascontiguousarray(vals, dtype=np.uint64)) if len(cols) else None
-        lengths = np.diff(row_ptr.astype(np.int64))
-        long_rows = np.nonzero(lengths > LONG_ROW)[0]
+        long_rows, item_ptr, items = long_row_items(row_ptr)
         self.n_long = int(long_rows.shape[0])
-        self.n_items = 0
+        self.n_items = int(items.shape[0])
         if self.n_long:
-            per_row = (lengths[long_rows] + ITEM - 1) // ITEM
-            item_ptr = np.zeros(self.n_long + 1, dtype=np.uint32)
-            np.cumsum(per_row, out=item_ptr[1:])
-            self.n_items = int(item_ptr[-1])
-            row_of = np.repeat(np.arange(self.n_long), per_row)
-            k_in_row = np.arange(self.n_items) - item_ptr[:-1].astype(np.int64)[row_of]
-            start = row_ptr[long_rows].astype(np.int64)[row_of] + k_in_row * ITEM
-            end = np.minimum(start + ITEM, row_ptr[long_rows + 1].astype(np.int64)[row_of])
-            items = np.stack([start, end], axis=1).astype(np.uint32)
-            self.long_rows = DeviceBuffer.from_numpy(long_rows.astype(np.uint32))
+            self.long_rows = DeviceBuffer.from_numpy(long_rows)
             self.item_ptr = DeviceBuffer.from_numpy(item_ptr)
-            self.items = DeviceBuffer.from_numpy(np.ascontiguousarray(items))
+            self.items = DeviceBuffer.from_numpy(items)
             self.partials = DeviceBuffer(self.n_items * 32)
 
     def apply(self, d_w, d_out, stream=None):
