@@ -75,11 +75,12 @@ class PointArray:
     def to_list(self):
         return list(self)
 
-    def plan(self, slot=0, precompute=False, high_priority=False):
+    def plan(self, slot=0, precompute=False, high_priority=False, window_bits=0):
         """device-resident bases + workspace (created on first use).  A second slot gives an independent
         workspace so two MSMs over the same key (tau_1 with u and with v) can be in flight together.
         precompute=True builds the fixed-base table 2^(c w) P_i (ZK_MSM_PRECOMPUTE): right for proving keys,
-        which are reused by every proof.  high_priority puts the plan's own stream at the top priority level."""
+        which are reused by every proof.  high_priority puts the plan's own stream at the top priority level;
+        window_bits 0 = the library's choice for len(self) points."""
         key = (slot, bool(precompute))
         if key not in self._plans:
             lib = N.ensure_gpu()
@@ -92,10 +93,11 @@ class PointArray:
                 flags = (N.MSM_PRECOMPUTE if precompute else 0) | (N.MSM_HIGH_PRIORITY if high_priority else 0)
                 if self.window_range is not None:
                     first, count = self.window_range
-                    N.check(lib.zk_msm_plan_create_range(self.curve_id, self.group, len(self), self.limbs.ctypes.data, 0, flags, 0,
-                                                         first, count, h))
+                    N.check(lib.zk_msm_plan_create_range(self.curve_id, self.group, len(self), self.limbs.ctypes.data, 0, flags,
+                                                         window_bits, first, count, h))
                 else:
-                    N.check(lib.zk_msm_plan_create(self.curve_id, self.group, len(self), self.limbs.ctypes.data, 0, flags, 0, h))
+                    N.check(lib.zk_msm_plan_create(self.curve_id, self.group, len(self), self.limbs.ctypes.data, 0, flags,
+                                                   window_bits, h))
             self._plans[key] = h.value
         return self._plans[key]
 
