@@ -7,6 +7,8 @@
 // g1()/g2(), and for get_evaluation_point / evaluate_lagrange_coefficients
 // (src/bn254/polynomial.rs:518-533,645-652).  The reference runs all of these on the CPU as
 // well: they touch one point (or O(n) scalars at setup time), not the proving hot path.
+#include <map>
+#include <mutex>
 #include <vector>
 #include "common.cuh"
 #include "curve_consts.h"
@@ -15,6 +17,128 @@ extern "C" void zk_ntt_free_cache(void);
 extern "C" void zk_msm_free_all(void);
 
 namespace zkmi {
+
+// ---- caching device allocator (common.cuh) ----------------------------------------------------------------
+static std::mutex g_cache_mutex;
+static std::multimap<size_t, void*> g_cache_free;          // size -> block
+static std::map<void*, size_t> g_cache_live;               // block -> size, for blocks handed out through the cache
+static size_t g_cache_bytes = 0;
+static const size_t CACHE_BUDGET = 6ull << 30;             // bytes kept for reuse
+static const size_t CACHE_MAX_BLOCK = 2ull << 30;          // larger blocks (fixed-base tables) are never kept
+
+int dev_alloc_cached(void** p, size_t bytes) {
+    if (bytes == 0) bytes = 1;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        auto it = g_cache_free.find(bytes);
+        if (it != g_cache_free.end()) {
+            *p = it->second;
+            g_cache_free.erase(it);
+            g_cache_bytes -= bytes;
+            g_cache_live[*p] = bytes;
+            return ZK_OK;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        dev_cache_release();  // give everything back and try once more
+        e = hipMalloc(p, bytes);
+    }
+    if (e != hipSuccess) return fail(ZK_ERR_HIP, std::string("hipMalloc(") + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    g_cache_live[*p] = bytes;
+    return ZK_OK;
+}
+
+void dev_free_cached(void* p) {
+    if (!p) return;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        auto it = g_cache_live.find(p);
+        if (it != g_cache_live.end()) {
+            bytes = it->second;
+            g_cache_live.erase(it);
+            if (bytes <= CACHE_MAX_BLOCK && g_cache_bytes + bytes <= CACHE_BUDGET) {
+                g_cache_free.emplace(bytes, p);
+                g_cache_bytes += bytes;
+                return;
+            }
+        }
+    }
+    (void)hipFree(p);
+}
+
+static std::vector<hipStream_t> g_stream_pool[2];
+static std::multimap<size_t, void*> g_pinned_free;
+static std::map<void*, size_t> g_pinned_live;
+
+void dev_cache_release() {
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    for (auto& kv : g_cache_free) (void)hipFree(kv.second);
+    g_cache_free.clear();
+    g_cache_bytes = 0;
+    for (auto& pool : g_stream_pool) {
+        for (hipStream_t st : pool) (void)hipStreamDestroy(st);
+        pool.clear();
+    }
+    for (auto& kv : g_pinned_free) (void)hipHostFree(kv.second);
+    g_pinned_free.clear();
+}
+
+int stream_acquire(bool high_priority, hipStream_t* out) {
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        auto& pool = g_stream_pool[high_priority ? 1 : 0];
+        if (!pool.empty()) {
+            *out = pool.back();
+            pool.pop_back();
+            return ZK_OK;
+        }
+    }
+    int lo = 0, hi = 0;
+    ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // numerically lower = higher priority
+    ZK_HIP(hipStreamCreateWithPriority(out, hipStreamDefault, high_priority ? hi : lo));
+    return ZK_OK;
+}
+
+void stream_release(bool high_priority, hipStream_t st) {
+    if (!st) return;
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    auto& pool = g_stream_pool[high_priority ? 1 : 0];
+    if (pool.size() < 32) pool.push_back(st);
+    else (void)hipStreamDestroy(st);
+}
+
+int pinned_alloc_cached(void** p, size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        auto it = g_pinned_free.find(bytes);
+        if (it != g_pinned_free.end()) {
+            *p = it->second;
+            g_pinned_free.erase(it);
+            g_pinned_live[*p] = bytes;
+            return ZK_OK;
+        }
+    }
+    ZK_HIP(hipHostMalloc(p, bytes));
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    g_pinned_live[*p] = bytes;
+    return ZK_OK;
+}
+
+void pinned_free_cached(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    auto it = g_pinned_live.find(p);
+    if (it != g_pinned_live.end() && g_pinned_free.size() < 64 && it->second <= (1u << 20)) {
+        g_pinned_free.emplace(it->second, p);
+        g_pinned_live.erase(it);
+        return;
+    }
+    if (it != g_pinned_live.end()) g_pinned_live.erase(it);
+    (void)hipHostFree(p);
+}
 
 template <class G> struct CurveConsts;
 template <> struct CurveConsts<Bn254G1> { static const uint32_t* gen() { return Bn254Consts::G1_GEN; } static const uint32_t* b() { return Bn254Consts::G1_B; } };
@@ -376,6 +500,7 @@ int zk_init(int device) {
 int zk_shutdown(void) {
     zk_msm_free_all();
     zk_ntt_free_cache();
+    dev_cache_release();
     return ZK_OK;
 }
 

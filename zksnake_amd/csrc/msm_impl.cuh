@@ -25,6 +25,7 @@
 //                  field multiplication, the host ~50 ns.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <memory>
 #include <vector>
 #include "common.cuh"
@@ -1089,7 +1090,7 @@ static int precompute_table(uint32_t* table, uint64_t n, int c, int w_first, int
     constexpr int AW = 2 * F::LIMBS, XW = 4 * F::LIMBS;
     if (w_first == 0 && w_count == 1) return ZK_OK;
     uint32_t* temp = nullptr;
-    ZK_HIP(hipMalloc(&temp, n * XW * 4));
+    ZK_ALLOC(&temp, n * XW * 4);
     const unsigned blocks = (unsigned)((n + 255) / 256);
     const unsigned nblocks = (unsigned)((n + (uint64_t)NORM_THREADS * NORM_E - 1) / ((uint64_t)NORM_THREADS * NORM_E));
     hipLaunchKernelGGL(dbl_rows_kernel<G>, dim3(blocks), dim3(256), 0, 0, temp, n, c * w_first, (const uint32_t*)table);
@@ -1100,7 +1101,7 @@ static int precompute_table(uint32_t* table, uint64_t n, int c, int w_first, int
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
-    (void)hipFree(temp);
+    dev_free_cached(temp);
     ZK_HIP(e);
     return ZK_OK;
 }
@@ -1118,7 +1119,7 @@ struct FixedTable {
     }
     void release() {
         std::lock_guard<std::mutex> lock(mu);
-        if (d_table) (void)hipFree(d_table);
+        if (d_table) dev_free_cached(d_table);
         d_table = nullptr;
         base.clear();
     }
@@ -1129,7 +1130,7 @@ struct FixedTable {
         constexpr int AW = 2 * F::LIMBS, XW = 4 * F::LIMBS;
         const size_t words64 = AW / 2;
         if (d_table && base.size() == words64 && memcmp(base.data(), base_limbs, words64 * 8) == 0) return ZK_OK;
-        if (d_table) (void)hipFree(d_table);
+        if (d_table) dev_free_cached(d_table);
         d_table = nullptr;
         base.clear();
         nwin = (FrP::BITS + 1 + FIXED_C - 1) / FIXED_C;
@@ -1148,9 +1149,9 @@ struct FixedTable {
         }
         const uint64_t rows = (uint64_t)nwin * FIXED_HALF;
         uint32_t *d_wb = nullptr, *temp = nullptr;
-        ZK_HIP(hipMalloc(&d_table, rows * AW * 4));
-        hipError_t e = hipMalloc(&d_wb, wb.size() * 4);
-        if (e == hipSuccess) e = hipMalloc(&temp, rows * XW * 4);
+        ZK_ALLOC(&d_table, rows * AW * 4);
+        hipError_t e = dev_alloc_cached((void**)&d_wb, wb.size() * 4) == ZK_OK ? hipSuccess : hipErrorOutOfMemory;
+        if (e == hipSuccess) e = dev_alloc_cached((void**)&temp, rows * XW * 4) == ZK_OK ? hipSuccess : hipErrorOutOfMemory;
         if (e == hipSuccess) e = hipMemcpy(d_wb, wb.data(), wb.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(fixed_table_kernel<G>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, 0, d_wb, nwin, temp);
@@ -1159,10 +1160,10 @@ struct FixedTable {
             e = hipGetLastError();
             if (e == hipSuccess) e = hipDeviceSynchronize();
         }
-        if (d_wb) (void)hipFree(d_wb);
-        if (temp) (void)hipFree(temp);
+        if (d_wb) dev_free_cached(d_wb);
+        if (temp) dev_free_cached(temp);
         if (e != hipSuccess) {
-            (void)hipFree(d_table);
+            dev_free_cached(d_table);
             d_table = nullptr;
             return fail(ZK_ERR_HIP, std::string("fixed-base table: ") + hipGetErrorString(e));
         }
@@ -1212,13 +1213,16 @@ struct MsmPlan : MsmPlanBase {
     hipEvent_t ev_start = nullptr, ev_digits = nullptr, ev_end = nullptr;
 
     ~MsmPlan() override {
+        // blocks go back to the caching allocator, which (unlike hipFree) does not wait for the device: make sure no run of
+        // this plan is still in flight
+        (void)hipDeviceSynchronize();
         void* bufs[] = {ws.hist, ws.total, ws.bstart, ws.sstart, ws.bsums, ws.grand, ws.big_list, ws.big_count,
                         ws.sorted, ws.partials, ws.buckets, ws.rows, ws.fin, ws.tmp_ref, ws.bin_start, ws.slice_sums, ws.bin_tot,
                         d_scalars, d_dig};
-        for (void* q : bufs) if (q) (void)hipFree(q);
-        if (h_final) (void)hipHostFree(h_final);
+        for (void* q : bufs) dev_free_cached(q);
+        pinned_free_cached(h_final);
         for (hipEvent_t e : {ws.ev_begin, ws.ev_acc0, ws.ev_acc1, ws.ev_done, ws.ev_release, ev_start, ev_digits, ev_end}) if (e) (void)hipEventDestroy(e);
-        if (own_stream) (void)hipStreamDestroy(own_stream);
+        stream_release((create_flags & ZK_MSM_HIGH_PRIORITY) != 0, own_stream);
     }
 
     // Every allocation lands in a member that the destructor frees, and the factory deletes the plan when init() fails
@@ -1226,6 +1230,14 @@ struct MsmPlan : MsmPlanBase {
     // `share` != nullptr: a clone -- same bases (and fixed-base table), own workspace and stream
     int init(uint64_t n_points, const void* bases, int bases_on_device, int flags, int window_bits, int win_first, int win_count,
              const MsmPlan* share = nullptr) {
+        static const bool trace = getenv("ZKMI_TRACE_INIT") != nullptr;
+        auto t_prev = std::chrono::steady_clock::now();
+        auto mark = [&](const char* what) {
+            if (!trace) return;
+            auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "[plan init] %-24s %8.1f us\n", what, std::chrono::duration<double, std::micro>(now - t_prev).count());
+            t_prev = now;
+        };
         create_flags = flags;
         pre = (flags & ZK_MSM_PRECOMPUTE) != 0;
         if (n_points == 0 || n_points > (1ull << 26)) return fail(ZK_ERR_ARG, "MSM size must be in [1, 2^26]");
@@ -1278,30 +1290,26 @@ struct MsmPlan : MsmPlanBase {
         const uint64_t entries = (uint64_t)pw_count * n;
         if (entries > 0x7FFFFFFFull) return fail(ZK_ERR_ARG, "MSM too large");
 
-        {
-            int lo = 0, hi = 0;
-            ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            ZK_HIP(hipStreamCreateWithPriority(&own_stream, hipStreamDefault, (flags & ZK_MSM_HIGH_PRIORITY) ? hi : lo));
-        }
+        ZK_HIP_RC(stream_acquire((flags & ZK_MSM_HIGH_PRIORITY) != 0, &own_stream));
         if (share) {
             bases_block = share->bases_block;
             d_bases = share->d_bases;
         } else {
             bases_block = std::make_shared<DeviceBlock>();
-            ZK_HIP(hipMalloc(&bases_block->ptr, (pre ? (uint64_t)pw_count : 1ull) * n * AW * 4));
+            ZK_ALLOC(&bases_block->ptr, (pre ? (uint64_t)pw_count : 1ull) * n * AW * 4);
             d_bases = (uint32_t*)bases_block->ptr;
             if (bases_on_device) {
                 hipLaunchKernelGGL(bases_to_mont_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0,
                                    (const uint32_t*)bases, n, d_bases);
             } else {
                 uint32_t* tmp = nullptr;
-                ZK_HIP(hipMalloc(&tmp, n * AW * 4));
+                ZK_ALLOC(&tmp, n * AW * 4);
                 hipError_t e = hipMemcpy(tmp, bases, n * AW * 4, hipMemcpyHostToDevice);
                 if (e == hipSuccess) {
                     hipLaunchKernelGGL(bases_to_mont_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, tmp, n, d_bases);
                     e = hipDeviceSynchronize();
                 }
-                (void)hipFree(tmp);
+                dev_free_cached(tmp);
                 ZK_HIP(e);
             }
             ZK_HIP(hipGetLastError());
@@ -1311,11 +1319,13 @@ struct MsmPlan : MsmPlanBase {
                 if (rc) return rc;
             }
         }
-        ZK_HIP(hipMalloc(&d_scalars, n * FrP::W * 4));
-        ZK_HIP(hipMalloc(&d_dig, (size_t)pw_count * (n + 8) * (wide ? 4 : 2)));
+        mark("stream + bases");
+        ZK_ALLOC(&d_scalars, n * FrP::W * 4);
+        ZK_ALLOC(&d_dig, (size_t)pw_count * (n + 8) * (wide ? 4 : 2));
         if (wide && !two_level_ok()) return fail(ZK_ERR_ARG, "this size does not fit the two-level sort that wide windows need");
         const uint64_t max_sets = pre ? 1ull : (uint64_t)pw_count;
-        ZK_HIP(hipHostMalloc(&h_final, (size_t)max_sets * (bpr + bpc) * 2 * XW * 4));
+        ZK_HIP_RC(pinned_alloc_cached((void**)&h_final, (size_t)max_sets * (bpr + bpc) * 2 * XW * 4));
+        mark("scalars/digits/pinned");
         for (hipEvent_t* e : {&ev_start, &ev_digits, &ev_end}) ZK_HIP(hipEventCreate(e));
         {
             const uint64_t keys = max_sets * B;
@@ -1323,27 +1333,28 @@ struct MsmPlan : MsmPlanBase {
             const uint32_t seg_full = pick_seg_len(entries);
             const uint64_t max_segs = std::max<uint64_t>(entries / seg_full, std::min<uint64_t>(entries / 8, SEG_TARGET_LANES)) + keys + 8;
             // windows x chunks <= max(256, windows) sub-histograms: of all B buckets (one-level sort) or of the coarse bins only
-            ZK_HIP(hipMalloc(&ws.hist, (size_t)std::max<uint64_t>(256, pw_count) * (wide ? (B >> fine_log_for(n)) : B) * 4));
-            ZK_HIP(hipMalloc(&ws.total, keys * 4));
-            ZK_HIP(hipMalloc(&ws.bstart, (keys + 1) * 4));
-            ZK_HIP(hipMalloc(&ws.sstart, (keys + 1) * 4));
-            ZK_HIP(hipMalloc(&ws.bsums, ((keys + SCAN_BLOCK - 1) / SCAN_BLOCK + 1) * 4));
-            ZK_HIP(hipMalloc(&ws.grand, 4));
-            ZK_HIP(hipMalloc(&ws.big_list, keys * 4));
-            ZK_HIP(hipMalloc(&ws.big_count, 8));
-            ZK_HIP(hipMalloc(&ws.sorted, entries * 4));
+            ZK_ALLOC(&ws.hist, (size_t)std::max<uint64_t>(256, pw_count) * (wide ? (B >> fine_log_for(n)) : B) * 4);
+            ZK_ALLOC(&ws.total, keys * 4);
+            ZK_ALLOC(&ws.bstart, (keys + 1) * 4);
+            ZK_ALLOC(&ws.sstart, (keys + 1) * 4);
+            ZK_ALLOC(&ws.bsums, ((keys + SCAN_BLOCK - 1) / SCAN_BLOCK + 1) * 4);
+            ZK_ALLOC(&ws.grand, 4);
+            ZK_ALLOC(&ws.big_list, keys * 4);
+            ZK_ALLOC(&ws.big_count, 8);
+            ZK_ALLOC(&ws.sorted, entries * 4);
             if (two_level_ok()) {
-                ZK_HIP(hipMalloc(&ws.tmp_ref, entries * 4));
-                ZK_HIP(hipMalloc(&ws.bin_start, (max_sets * (B >> fine_log_for(n)) + 1) * 4));
-                ZK_HIP(hipMalloc(&ws.slice_sums, 4096 * BINS_SLICES * 4));
-                ZK_HIP(hipMalloc(&ws.bin_tot, 4096 * 4));
+                ZK_ALLOC(&ws.tmp_ref, entries * 4);
+                ZK_ALLOC(&ws.bin_start, (max_sets * (B >> fine_log_for(n)) + 1) * 4);
+                ZK_ALLOC(&ws.slice_sums, 4096 * BINS_SLICES * 4);
+                ZK_ALLOC(&ws.bin_tot, 4096 * 4);
             }
-            ZK_HIP(hipMalloc(&ws.partials, max_segs * XW * 4));
-            ZK_HIP(hipMalloc(&ws.buckets, keys * XW * 4));
-            ZK_HIP(hipMalloc(&ws.rows, max_sets * (R + C) * XW * 4));
-            ZK_HIP(hipMalloc(&ws.fin, max_sets * (bpr + bpc) * 2 * XW * 4));
+            ZK_ALLOC(&ws.partials, max_segs * XW * 4);
+            ZK_ALLOC(&ws.buckets, keys * XW * 4);
+            ZK_ALLOC(&ws.rows, max_sets * (R + C) * XW * 4);
+            ZK_ALLOC(&ws.fin, max_sets * (bpr + bpc) * 2 * XW * 4);
             for (hipEvent_t* e : {&ws.ev_begin, &ws.ev_acc0, &ws.ev_acc1, &ws.ev_done, &ws.ev_release}) ZK_HIP(hipEventCreate(e));
         }
+        mark("workspace + events");
         // LDS above 64 KiB needs the opt-in
         int lds_bytes = (int)((wide ? (1u << 15) : B) * 4);  // the one-level kernels never run for wide windows
         ZK_HIP(hipFuncSetAttribute((const void*)hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
@@ -1355,7 +1366,9 @@ struct MsmPlan : MsmPlanBase {
         ZK_HIP(hipFuncSetAttribute((const void*)sort_lo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
         ZK_HIP(hipFuncSetAttribute((const void*)weighted_sum_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(HalfRegs<F>::COUNT * HS_THREADS * 4)));
+        mark("func attributes");
         ZK_HIP(hipDeviceSynchronize());
+        mark("device sync");
         return ZK_OK;
     }
 
@@ -1723,9 +1736,9 @@ static int batch_mul_impl(uint64_t n, const uint64_t* scalars, const uint64_t* b
     int rc = ZK_OK;
     const bool fixed = broadcast && n >= FIXED_BASE_MIN;
     uint64_t nb = broadcast ? 1 : n;
-    ZK_HIP(hipMalloc(&ds, n * FrP::W * 4));
+    ZK_ALLOC(&ds, n * FrP::W * 4);
     do {
-        if (hipMalloc(&temp, n * XW * 4) != hipSuccess || hipMalloc(&dout, n * AW * 4) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMalloc failed"); break; }
+        if (dev_alloc_cached((void**)&temp, n * XW * 4) != ZK_OK || dev_alloc_cached((void**)&dout, n * AW * 4) != ZK_OK) { rc = ZK_ERR_HIP; break; }
         if (hipMemcpy(ds, scalars, n * FrP::W * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy H2D failed"); break; }
         if (fixed) {
             FixedTable<G>& ft = FixedTable<G>::get();
@@ -1740,7 +1753,7 @@ static int batch_mul_impl(uint64_t n, const uint64_t* scalars, const uint64_t* b
             hipLaunchKernelGGL(fixed_mul_kernel<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ds, n, ft.d_table, ft.nwin, bias, temp);
             if (hipDeviceSynchronize() != hipSuccess) { rc = fail(ZK_ERR_HIP, "fixed-base multiplication kernel failed"); break; }
         } else {
-            if (hipMalloc(&db, nb * AW * 4) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMalloc failed"); break; }
+            if (dev_alloc_cached((void**)&db, nb * AW * 4) != ZK_OK) { rc = ZK_ERR_HIP; break; }
             if (hipMemcpy(db, bases, nb * AW * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy H2D failed"); break; }
             hipLaunchKernelGGL(varbase_mul_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, ds, db, broadcast, n, temp);
         }
@@ -1748,7 +1761,7 @@ static int batch_mul_impl(uint64_t n, const uint64_t* scalars, const uint64_t* b
                            dim3(NORM_THREADS), 0, 0, temp, n, dout, 1);
         if (hipGetLastError() != hipSuccess || hipMemcpy(out, dout, n * AW * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "batch_mul kernel / D2H failed"); break; }
     } while (0);
-    (void)hipFree(ds); (void)hipFree(db); (void)hipFree(dout); (void)hipFree(temp);
+    dev_free_cached(ds); dev_free_cached(db); dev_free_cached(dout); dev_free_cached(temp);
     return rc;
 }
 

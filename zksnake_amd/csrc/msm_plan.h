@@ -8,11 +8,10 @@
 namespace zkmi {
 
 // a device allocation with shared ownership (the bases / fixed-base table of a plan and its clones)
+void dev_free_cached(void* p);  // common.cuh / host.hip
 struct DeviceBlock {
     void* ptr = nullptr;
-    ~DeviceBlock() {
-        if (ptr) (void)hipFree(ptr);
-    }
+    ~DeviceBlock() { dev_free_cached(ptr); }
 };
 
 // what a plan with a run in flight lends to a second plan that multiplies the SAME scalars against other bases of the

@@ -517,7 +517,7 @@ static int ntt_host_impl(int curve, int inverse, int coset, uint64_t n_in, const
     // DensePolynomial::evaluate_over_domain folds modulo X^n - 1, and the reference does not call it on this path.
     if (n_in > n) n_in = n;
     const uint64_t alloc = n;
-    ZK_HIP(hipMalloc(&d, alloc * eb));
+    ZK_ALLOC(&d, alloc * eb);
     int rc = ZK_OK;
     do {
         if (hipMemset(d, 0, alloc * eb) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemset failed"); break; }
@@ -529,7 +529,7 @@ static int ntt_host_impl(int curve, int inverse, int coset, uint64_t n_in, const
         if (coset && inverse) { rc = coset_scale_impl<P>(curve, 1, log_n, d, 0); if (rc) break; }
         if (hipMemcpy(out, d, n * eb, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy D2H failed"); break; }
     } while (0);
-    (void)hipFree(d);
+    dev_free_cached(d);
     return rc;
 }
 
@@ -538,7 +538,7 @@ static int vec_op_host_impl(int op, uint64_t size, uint64_t n_a, const uint64_t*
     if (size == 0) return ZK_OK;
     const size_t eb = P::W * 4;
     uint32_t* d = nullptr;
-    ZK_HIP(hipMalloc(&d, 2 * size * eb));
+    ZK_ALLOC(&d, 2 * size * eb);
     int rc = ZK_OK;
     do {
         if (hipMemset(d, 0, 2 * size * eb) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemset failed"); break; }
@@ -550,7 +550,7 @@ static int vec_op_host_impl(int op, uint64_t size, uint64_t n_a, const uint64_t*
         if (rc) break;
         if (hipMemcpy(out, d, size * eb, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy D2H failed"); break; }
     } while (0);
-    (void)hipFree(d);
+    dev_free_cached(d);
     return rc;
 }
 
@@ -563,11 +563,11 @@ static int div_vanishing_host_impl(uint64_t n, uint64_t len, const uint64_t* coe
     uint64_t qlen = len > n ? len - n : 0, top = len < n ? len : n;
     uint32_t *dc = nullptr, *dq = nullptr, *dr = nullptr;
     int* dflag = nullptr;
-    ZK_HIP(hipMalloc(&dc, len * eb));
+    ZK_ALLOC(&dc, len * eb);
     int rc = ZK_OK;
     do {
-        if (hipMalloc(&dq, (qlen ? qlen : 1) * eb) != hipSuccess || hipMalloc(&dr, top * eb) != hipSuccess ||
-            hipMalloc(&dflag, sizeof(int)) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMalloc failed"); break; }
+        if (dev_alloc_cached((void**)&dq, (qlen ? qlen : 1) * eb) != ZK_OK || dev_alloc_cached((void**)&dr, top * eb) != ZK_OK ||
+            dev_alloc_cached((void**)&dflag, sizeof(int)) != ZK_OK) { rc = fail(ZK_ERR_HIP, "hipMalloc failed"); break; }
         if (hipMemcpy(dc, coeffs, len * eb, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy H2D failed"); break; }
         (void)hipMemset(dflag, 0, sizeof(int));
         hipLaunchKernelGGL(canon_kernel<P>, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, 0, len, dc);
@@ -579,7 +579,7 @@ static int div_vanishing_host_impl(uint64_t n, uint64_t len, const uint64_t* coe
         if (hipMemcpy(rem, dr, top * eb, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy D2H failed"); break; }
         *rem_is_zero = flag ? 0 : 1;
     } while (0);
-    (void)hipFree(dc); (void)hipFree(dq); (void)hipFree(dr); (void)hipFree(dflag);
+    dev_free_cached(dc); dev_free_cached(dq); dev_free_cached(dr); dev_free_cached(dflag);
     return rc;
 }
 
