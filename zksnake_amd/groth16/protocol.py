@@ -304,7 +304,9 @@ class Groth16:
         if isinstance(public_witness, np.ndarray):
             public_witness = N.limbs_to_ints(public_witness)
         sum_gamma_witness = self.E.multiexp(vk.ic, public_witness)
-        # e(A, B) == e(alpha, beta) * e(sum_gamma_witness, gamma) * e(C, delta)
-        lhs = self.E.pairing(proof.A, proof.B)
-        rhs = self.E.multi_pairing([vk.alpha_1, sum_gamma_witness, proof.C], [vk.beta_2, vk.gamma_2, vk.delta_2])
-        return lhs == rhs
+        # e(A, B) == e(alpha, beta) * e(sum_gamma_witness, gamma) * e(C, delta)  (protocol.py:176-186), checked as
+        # e(-A, B) * e(alpha, beta) * e(sum_gamma_witness, gamma) * e(C, delta) == 1: the same predicate through ONE
+        # multi-pairing, i.e. one final exponentiation (the expensive half of the host-side pairing) instead of two
+        prod = self.E.multi_pairing([-proof.A, vk.alpha_1, sum_gamma_witness, proof.C],
+                                    [proof.B, vk.beta_2, vk.gamma_2, vk.delta_2])
+        return prod.is_one()

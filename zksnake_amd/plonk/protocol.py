@@ -401,6 +401,7 @@ class Plonk:
         rhs_point = terms[0][0] * (terms[0][1] % r)
         for point, scalar in terms[1:]:
             rhs_point = rhs_point + point * (scalar % r)
-        lhs = self.E.pairing(proof.tau_W_zeta + proof.tau_W_zeta_omega * u, vk.tau_g2)
-        rhs = self.E.pairing(rhs_point, self.E.G2())
-        return lhs == rhs
+        # e(W_zeta + u W_zeta_omega, tau G2) == e(rhs, G2)  (protocol.py:640-647), checked as a product equal to one:
+        # one multi-pairing, one final exponentiation
+        lhs_point = proof.tau_W_zeta + proof.tau_W_zeta_omega * u
+        return self.E.multi_pairing([lhs_point, -rhs_point], [vk.tau_g2, self.E.G2()]).is_one()
