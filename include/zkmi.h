@@ -194,6 +194,14 @@ int zk_point_generator(int curve, int group, uint64_t* out);                    
 /* to_bytes / from_bytes = ark-serialize compressed (curve.rs:127-146): 32/64 B (BN254), 48/96 B (BLS12-381) */
 int zk_point_compress(int curve, int group, const uint64_t* a, uint8_t* out);
 int zk_point_decompress(int curve, int group, const uint8_t* in, uint64_t* out);
+
+/* The same for the point vectors of a key file (python/zksnake/groth16/serialization.py:60-141 loops to_bytes /
+ * from_hex over tau_1, tau_2, target_1, kdelta_1; plonk/serialization.py likewise): n points, one per GPU lane,
+ * between host buffers of n * zk_point_limbs words and n * zk_point_bytes bytes.  Decoding validates like
+ * zk_point_decompress (flags, x < p, on the curve, prime-order subgroup).  On ZK_ERR_POINT the message is that of the
+ * FIRST offending point and *bad_index (may be NULL) its index. */
+int zk_points_compress(int curve, int group, uint64_t n, const uint64_t* points, uint8_t* out, uint64_t* bad_index);
+int zk_points_decompress(int curve, int group, uint64_t n, const uint8_t* in, uint64_t* out, uint64_t* bad_index);
 int zk_point_bytes(int curve, int group);
 
 /* ---- PlonK prover, device-resident vector kernels (csrc/plonk.hip) ----

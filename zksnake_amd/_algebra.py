@@ -75,6 +75,37 @@ class PointArray:
     def to_list(self):
         return list(self)
 
+    # below this many points the per-point host codec is used (no GPU needed: a verifying key's few ic points)
+    BATCH_CODEC_MIN = 64
+
+    def to_bytes(self):
+        """the points' compressed encodings back to back (what `b"".join(p.to_bytes() for p in points)` gives)"""
+        lib = N.load()
+        nb = lib.zk_point_bytes(self.curve_id, self.group)
+        out = np.zeros(len(self) * nb, dtype=np.uint8)
+        if len(self) >= self.BATCH_CODEC_MIN:
+            N.ensure_gpu()
+            N.check(lib.zk_points_compress(self.curve_id, self.group, len(self), N.u64p(self.limbs), N.u8p(out), None))
+        else:
+            for i, row in enumerate(self.limbs):
+                N.check(lib.zk_point_compress(self.curve_id, self.group, N.u64p(row), N.u8p(out[i * nb:(i + 1) * nb])))
+        return out.tobytes()
+
+    @classmethod
+    def from_compressed(cls, curve_id, group, data, count):
+        """`count` compressed points read from `data`, validated like from_hex (flags, range, curve, subgroup)"""
+        lib = N.load()
+        nb = lib.zk_point_bytes(curve_id, group)
+        raw = np.frombuffer(data, dtype=np.uint8, count=count * nb)
+        limbs = np.zeros((count, N.point_limbs(curve_id, group)), dtype=np.uint64)
+        if count >= cls.BATCH_CODEC_MIN:
+            N.ensure_gpu()
+            N.check(lib.zk_points_decompress(curve_id, group, count, N.u8p(raw), N.u64p(limbs), None))
+        else:
+            for i in range(count):
+                N.check(lib.zk_point_decompress(curve_id, group, N.u8p(raw[i * nb:(i + 1) * nb]), N.u64p(limbs[i])))
+        return cls(curve_id, group, limbs)
+
     def plan(self, slot=0, precompute=False, high_priority=False, window_bits=0):
         """device-resident bases + workspace (created on first use).  A second slot gives an independent
         workspace so two MSMs over the same key (tau_1 with u and with v) can be in flight together.

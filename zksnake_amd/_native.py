@@ -88,6 +88,8 @@ SIGNATURES = {
     "zk_point_generator": (_i, [_i, _i, _u64p]),
     "zk_point_compress": (_i, [_i, _i, _u64p, _u8p]),
     "zk_point_decompress": (_i, [_i, _i, _u8p, _u64p]),
+    "zk_points_compress": (_i, [_i, _i, _u64, _u64p, _u8p, _u64p]),
+    "zk_points_decompress": (_i, [_i, _i, _u64, _u8p, _u64p, _u64p]),
     "zk_point_bytes": (_i, [_i, _i]),
     "zk_vec_axpby_dev": (_i, [_i, _u64, _u64p, _vp, _u64p, _vp, _u64p, _vp, _vp]),
     "zk_vec_gather_dev": (_i, [_i, _u64, _vp, _u64, _u64, _vp, _vp]),

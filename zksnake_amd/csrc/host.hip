@@ -11,7 +11,7 @@
 #include <mutex>
 #include <vector>
 #include "common.cuh"
-#include "curve_consts.h"
+#include "codec.cuh"
 
 extern "C" void zk_ntt_free_cache(void);
 extern "C" void zk_msm_free_all(void);
@@ -140,11 +140,6 @@ void pinned_free_cached(void* p) {
     (void)hipHostFree(p);
 }
 
-template <class G> struct CurveConsts;
-template <> struct CurveConsts<Bn254G1> { static const uint32_t* gen() { return Bn254Consts::G1_GEN; } static const uint32_t* b() { return Bn254Consts::G1_B; } };
-template <> struct CurveConsts<Bn254G2> { static const uint32_t* gen() { return Bn254Consts::G2_GEN; } static const uint32_t* b() { return Bn254Consts::G2_B; } };
-template <> struct CurveConsts<Bls381G1> { static const uint32_t* gen() { return Bls381Consts::G1_GEN; } static const uint32_t* b() { return Bls381Consts::G1_B; } };
-template <> struct CurveConsts<Bls381G2> { static const uint32_t* gen() { return Bls381Consts::G2_GEN; } static const uint32_t* b() { return Bls381Consts::G2_B; } };
 
 template <class G>
 static Affine<typename G::F> load_point(const uint64_t* src) {
@@ -194,161 +189,18 @@ static void reduce_scalar(uint32_t* k, const uint64_t* scalar) {
     }
 }
 
-// ---- square roots (both base fields have p = 3 mod 4) ---------------------------------------------
-
-template <class P>
-static bool fp_sqrt(const Fp<P>& a, Fp<P>* out) {
-    Fp<P> s = fp_pow<P>(a, P::SQRT_E, P::W);
-    if (!fp_eq<P>(fp_sqr<P>(s), a)) return false;
-    *out = s;
-    return true;
-}
-
-template <class P>
-static bool fp2_sqrt(const Fp2<P>& a, Fp2<P>* out) {
-    if (fp2_is_zero<P>(a)) { *out = a; return true; }
-    Fp<P> s;
-    if (fp_is_zero<P>(a.c1)) {
-        if (fp_sqrt<P>(a.c0, &s)) { *out = {s, fp_zero<P>()}; return true; }
-        if (fp_sqrt<P>(fp_neg<P>(a.c0), &s)) { *out = {fp_zero<P>(), s}; return true; }
-        return false;
-    }
-    Fp<P> norm = fp_add<P>(fp_sqr<P>(a.c0), fp_sqr<P>(a.c1));
-    Fp<P> alpha;
-    if (!fp_sqrt<P>(norm, &alpha)) return false;
-    Fp<P> two = fp_dbl<P>(fp_one<P>());
-    Fp<P> inv2 = fp_inv<P>(two);
-    Fp<P> delta = fp_mul<P>(fp_add<P>(a.c0, alpha), inv2);
-    Fp<P> x0;
-    if (!fp_sqrt<P>(delta, &x0)) {
-        delta = fp_mul<P>(fp_sub<P>(a.c0, alpha), inv2);
-        if (!fp_sqrt<P>(delta, &x0)) return false;
-    }
-    Fp<P> x1 = fp_mul<P>(a.c1, fp_inv<P>(fp_dbl<P>(x0)));
-    Fp2<P> cand = {x0, x1};
-    if (!fp2_eq<P>(fp2_sqr<P>(cand), a)) return false;
-    *out = cand;
-    return true;
-}
-
-template <class P> static bool coord_sqrt(const Fp<P>& a, Fp<P>* o) { return fp_sqrt<P>(a, o); }
-template <class P> static bool coord_sqrt(const Fp2<P>& a, Fp2<P>* o) { return fp2_sqrt<P>(a, o); }
-
-// "y is the lexicographically larger of {y, -y}" (ark: y > -y; Fp2 compares c1 first, then c0)
-template <class P>
-static bool coord_is_larger(const Fp<P>& y) {
-    uint32_t c[P::W];
-    fp_to_canonical<P>(c, y);
-    return fp_canonical_gt_half<P>(c);
-}
-template <class P>
-static bool coord_is_larger(const Fp2<P>& y) {
-    if (!fp_is_zero<P>(y.c1)) return coord_is_larger<P>(y.c1);
-    return coord_is_larger<P>(y.c0);
-}
-
-// ---- compressed encodings ---------------------------------------------------------------------------
-
-static void words_to_bytes(uint8_t* dst, const uint32_t* w, int nbytes, bool big_endian) {
-    for (int i = 0; i < nbytes; ++i) {
-        uint8_t b = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
-        dst[big_endian ? nbytes - 1 - i : i] = b;
-    }
-}
-static void bytes_to_words(uint32_t* w, int nwords, const uint8_t* src, int nbytes, bool big_endian) {
-    for (int i = 0; i < nwords; ++i) w[i] = 0;
-    for (int i = 0; i < nbytes; ++i) {
-        uint8_t b = src[big_endian ? nbytes - 1 - i : i];
-        w[i >> 2] |= (uint32_t)b << (8 * (i & 3));
-    }
-}
-template <class P>
-static bool canonical_lt_mod(const uint32_t* c) {
-    uint32_t t[P::W];
-    return fp_sub_mod_raw<P>(t, c) != 0;
-}
+// ---- compressed encodings (codec.cuh holds the arithmetic, shared with the batched GPU kernels) ----------
 
 template <class G>
 static int compress_impl(const uint64_t* a, uint8_t* out) {
-    typedef typename G::F F;
-    typedef typename F::Params P;
-    constexpr bool bls = G::CURVE == ZK_CURVE_BLS12_381;
-    constexpr int fb = bls ? 48 : 32;            // bytes per base-field element
-    constexpr int comps = F::LIMBS / P::W;       // 1 (G1) or 2 (G2)
-    constexpr int total = fb * comps;
-    Affine<F> p = load_point<G>(a);
-    memset(out, 0, total);
-    if (aff_is_inf<F>(p)) {
-        if (bls) out[0] = 0xC0; else out[total - 1] = 0x40;
-        return ZK_OK;
-    }
-    if (!point_on_curve<G>(p)) return fail(ZK_ERR_POINT, "point is not on the curve");
-    const uint32_t* xw = reinterpret_cast<const uint32_t*>(a);
-    bool larger = coord_is_larger(p.y);
-    if (bls) {
-        // zcash: big-endian, c1 first for Fp2; bit7 compressed, bit6 infinity, bit5 y-largest
-        for (int k = 0; k < comps; ++k) words_to_bytes(out + k * fb, xw + (comps - 1 - k) * P::W, fb, true);
-        out[0] |= 0x80;
-        if (larger) out[0] |= 0x20;
-    } else {
-        // ark-serialize: little-endian, c0 first; flags in the top bits of the last byte
-        for (int k = 0; k < comps; ++k) words_to_bytes(out + k * fb, xw + k * P::W, fb, false);
-        if (larger) out[total - 1] |= 0x80;
-    }
-    return ZK_OK;
+    int code = point_encode<G>(reinterpret_cast<const uint32_t*>(a), out);
+    return code ? fail(ZK_ERR_POINT, codec_message(code)) : ZK_OK;
 }
 
 template <class G>
 static int decompress_impl(const uint8_t* in, uint64_t* out) {
-    typedef typename G::F F;
-    typedef typename F::Params P;
-    typedef typename G::Fr FrP;
-    constexpr bool bls = G::CURVE == ZK_CURVE_BLS12_381;
-    constexpr int fb = bls ? 48 : 32;
-    constexpr int comps = F::LIMBS / P::W;
-    constexpr int total = fb * comps;
-    uint8_t buf[total];
-    memcpy(buf, in, total);
-    bool inf, larger;
-    if (bls) {
-        uint8_t flags = buf[0] & 0xE0;
-        buf[0] &= 0x1F;
-        if (!(flags & 0x80)) return fail(ZK_ERR_POINT, "Cannot deserialize point: uncompressed encoding");
-        inf = flags & 0x40;
-        larger = flags & 0x20;
-    } else {
-        uint8_t flags = buf[total - 1] & 0xC0;
-        buf[total - 1] &= 0x3F;
-        if (flags == 0xC0) return fail(ZK_ERR_POINT, "Cannot deserialize point: invalid flags");
-        inf = flags & 0x40;
-        larger = flags & 0x80;
-    }
-    uint32_t xw[F::LIMBS];
-    for (int k = 0; k < comps; ++k) {
-        if (bls) bytes_to_words(xw + (comps - 1 - k) * P::W, P::W, buf + k * fb, fb, true);
-        else bytes_to_words(xw + k * P::W, P::W, buf + k * fb, fb, false);
-    }
-    if (inf) {
-        for (int i = 0; i < F::LIMBS; ++i)
-            if (xw[i]) return fail(ZK_ERR_POINT, "Cannot deserialize point: non-zero x with the infinity flag");
-        if (larger) return fail(ZK_ERR_POINT, "Cannot deserialize point: invalid flags");
-        memset(out, 0, (size_t)2 * F::LIMBS * 4);
-        return ZK_OK;
-    }
-    for (int k = 0; k < comps; ++k)
-        if (!canonical_lt_mod<P>(xw + k * P::W)) return fail(ZK_ERR_POINT, "Cannot deserialize point: x is not a field element");
-    typename F::T x = F::from_canonical(xw);
-    typename F::T rhs = F::add(F::mul(F::sqr(x), x), F::from_canonical(CurveConsts<G>::b()));
-    typename F::T y;
-    if (!coord_sqrt(rhs, &y)) return fail(ZK_ERR_POINT, "Cannot deserialize point: x is not on the curve");
-    if (coord_is_larger(y) != larger) y = F::neg(y);
-    Affine<F> p = {x, y};
-    // subgroup check (ark's deserialize_compressed validates): r * P == infinity
-    uint32_t r[FrP::W];
-    memcpy(r, FrP::MOD, sizeof(r));
-    if (!xyzz_is_inf<F>(xyzz_scalar_mul<F>(p, r, FrP::W))) return fail(ZK_ERR_POINT, "Cannot deserialize point: not in the prime-order subgroup");
-    store_point<G>(out, p);
-    return ZK_OK;
+    int code = point_decode<G>(in, reinterpret_cast<uint32_t*>(out));
+    return code ? fail(ZK_ERR_POINT, codec_message(code)) : ZK_OK;
 }
 
 // ---- scalar-field helpers ---------------------------------------------------------------------------

@@ -168,6 +168,23 @@ int zk_batch_mul(int curve, int group, uint64_t n, const uint64_t* scalars, cons
     return fail(ZK_ERR_ARG, "unknown curve/group");
 }
 
+static int points_codec(int curve, int group, uint64_t n, const void* in, void* out, int to_bytes, uint64_t* bad_index) {
+    if (bad_index) *bad_index = ~0ull;
+    if (curve == ZK_CURVE_BN254 && group == ZK_G1) return msm_points_codec_Bn254G1(n, in, out, to_bytes, bad_index);
+    if (curve == ZK_CURVE_BN254 && group == ZK_G2) return msm_points_codec_Bn254G2(n, in, out, to_bytes, bad_index);
+    if (curve == ZK_CURVE_BLS12_381 && group == ZK_G1) return msm_points_codec_Bls381G1(n, in, out, to_bytes, bad_index);
+    if (curve == ZK_CURVE_BLS12_381 && group == ZK_G2) return msm_points_codec_Bls381G2(n, in, out, to_bytes, bad_index);
+    return fail(ZK_ERR_ARG, "unknown curve/group");
+}
+
+int zk_points_compress(int curve, int group, uint64_t n, const uint64_t* points, uint8_t* out, uint64_t* bad_index) {
+    return points_codec(curve, group, n, points, out, 1, bad_index);
+}
+
+int zk_points_decompress(int curve, int group, uint64_t n, const uint8_t* in, uint64_t* out, uint64_t* bad_index) {
+    return points_codec(curve, group, n, in, out, 0, bad_index);
+}
+
 void zk_msm_free_all(void) {
     std::lock_guard<std::mutex> lock(g_plan_mutex);
     for (auto& kv : g_plans) delete kv.second;

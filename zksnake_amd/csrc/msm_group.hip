@@ -4,7 +4,8 @@
 //   ZK_PART 0: the plan (host code) and the small kernels; the heavy kernels are only declared (extern template)
 //   ZK_PART 1: accumulate / bases_to_mont kernels
 //   ZK_PART 2: combine (3 tiers) / strided_sum / weighted_sum kernels
-//   ZK_PART 3: setup-side kernels (batched normalisation, fixed-base table rows, batch scalar multiplication)
+//   ZK_PART 3: setup-side kernels (batched normalisation, fixed-base table rows, batch scalar multiplication,
+//              batched point (de)compression)
 #include "msm_impl.cuh"
 
 #ifndef ZK_GROUP
@@ -27,6 +28,7 @@ template __global__ void strided_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t*
 template __global__ void weighted_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t, uint32_t, const uint32_t*, uint32_t, uint32_t*);
 #elif ZK_PART == 3
 ZK_SETUP_INSTANTIATE(ZK_GROUP)
+ZK_CODEC_INSTANTIATE(ZK_GROUP)
 #else
 
 int ZK_CAT(msm_plan_create_, ZK_GROUP)(uint64_t n, const void* bases, int on_device, int flags, int window_bits,
@@ -46,6 +48,10 @@ void ZK_CAT(msm_fixed_table_free_, ZK_GROUP)() { FixedTable<ZK_GROUP>::get().rel
 int ZK_CAT(msm_batch_mul_, ZK_GROUP)(uint64_t n, const uint64_t* scalars, const uint64_t* bases, int broadcast,
                                      uint64_t* out) {
     return batch_mul_impl<ZK_GROUP>(n, scalars, bases, broadcast, out);
+}
+
+int ZK_CAT(msm_points_codec_, ZK_GROUP)(uint64_t n, const void* in, void* out, int to_bytes, uint64_t* bad_index) {
+    return codec_impl<ZK_GROUP>(n, in, out, to_bytes, bad_index);
 }
 
 #endif

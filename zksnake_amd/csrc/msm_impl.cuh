@@ -32,6 +32,7 @@
 #include "msm_plan.h"
 #include "pair.cuh"
 #include "setup_impl.cuh"
+#include "codec.cuh"
 
 namespace zkmi {
 
@@ -1064,6 +1065,7 @@ extern template __global__ void combine_kernel<ZK_GROUP>(const uint32_t*, const 
 extern template __global__ void strided_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t*, SumJob, SumJob, uint32_t);
 extern template __global__ void weighted_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t, uint32_t, const uint32_t*, uint32_t, uint32_t*);
 ZK_SETUP_EXTERN_TEMPLATES(ZK_GROUP)
+ZK_CODEC_EXTERN_TEMPLATES(ZK_GROUP)
 #endif
 
 #if !defined(ZK_PART) || ZK_PART == 0
@@ -1762,6 +1764,40 @@ static int batch_mul_impl(uint64_t n, const uint64_t* scalars, const uint64_t* b
         if (hipGetLastError() != hipSuccess || hipMemcpy(out, dout, n * AW * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "batch_mul kernel / D2H failed"); break; }
     } while (0);
     dev_free_cached(ds); dev_free_cached(db); dev_free_cached(dout); dev_free_cached(temp);
+    return rc;
+}
+
+// batched (de)compression of n points between host buffers: `to_bytes` != 0 encodes canonical affine rows, 0 decodes.
+// On a failing point the first one (lowest index) decides the error, as a sequential loop over the file would.
+template <class G>
+static int codec_impl(uint64_t n, const void* in, void* out, int to_bytes, uint64_t* bad_index) {
+    typedef typename G::F F;
+    constexpr size_t ROW = (size_t)2 * F::LIMBS * 4, ENC = CodecLayout<G>::TOTAL;
+    if (n == 0) return ZK_OK;
+    const size_t in_bytes = n * (to_bytes ? ROW : ENC), out_bytes = n * (to_bytes ? ENC : ROW);
+    uint8_t *din = nullptr, *dout = nullptr;
+    unsigned long long* derr = nullptr;
+    int rc = ZK_OK;
+    ZK_ALLOC(&din, in_bytes);
+    do {
+        if (dev_alloc_cached((void**)&dout, out_bytes) != ZK_OK || dev_alloc_cached((void**)&derr, 8) != ZK_OK) { rc = ZK_ERR_HIP; break; }
+        unsigned long long first = ~0ull;
+        if (hipMemcpy(din, in, in_bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(derr, &first, 8, hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(ZK_ERR_HIP, "hipMemcpy H2D failed");
+            break;
+        }
+        const dim3 grid((unsigned)((n + 127) / 128)), block(128);
+        if (to_bytes) hipLaunchKernelGGL(points_encode_kernel<G>, grid, block, 0, 0, (const uint32_t*)din, n, dout, derr);
+        else hipLaunchKernelGGL(points_decode_kernel<G>, grid, block, 0, 0, (const uint8_t*)din, n, (uint32_t*)dout, derr);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(&first, derr, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "point codec kernel failed"); break; }
+        if (first != ~0ull) {
+            if (bad_index) *bad_index = (uint64_t)(first >> 8);
+            rc = fail(ZK_ERR_POINT, codec_message((int)(first & 0xFF)));
+            break;
+        }
+        if (hipMemcpy(out, dout, out_bytes, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemcpy D2H failed"); break; }
+    } while (0);
+    dev_free_cached(din); dev_free_cached(dout); dev_free_cached(derr);
     return rc;
 }
 

@@ -55,6 +55,7 @@ struct MsmPlanBase {
     int msm_plan_create_##G(uint64_t n, const void* bases, int on_device, int flags, int window_bits, int window_first,    \
                             int window_count, MsmPlanBase** out);                                                        \
     int msm_batch_mul_##G(uint64_t n, const uint64_t* scalars, const uint64_t* bases, int broadcast, uint64_t* out);     \
+    int msm_points_codec_##G(uint64_t n, const void* in, void* out, int to_bytes, uint64_t* bad_index);                  \
     void msm_fixed_table_free_##G();
 ZK_DECLARE_GROUP(Bn254G1)
 ZK_DECLARE_GROUP(Bn254G2)

@@ -51,6 +51,7 @@ class EllipticCurve:
         self.name = curve
         self.curve = _module(curve)  # KeyError for an unknown name, like the reference's Enum lookup
         bn = curve in _BN
+        self.curve_id = 0 if bn else 1  # ZK_CURVE_BN254 / ZK_CURVE_BLS12_381
         self.order = BN254_SCALAR_FIELD if bn else BLS12_381_SCALAR_FIELD
         self.field_modulus = BN254_MODULUS if bn else BLS12_381_MODULUS
 

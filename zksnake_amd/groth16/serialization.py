@@ -19,14 +19,7 @@ from ..ecc import CurvePointSize, EllipticCurve
 
 def _compress_many(points):
     if isinstance(points, PointArray):
-        lib = N.load()
-        nb = lib.zk_point_bytes(points.curve_id, points.group)
-        out = bytearray()
-        buf = np.zeros(nb, dtype=np.uint8)
-        for row in points.limbs:
-            N.check(lib.zk_point_compress(points.curve_id, points.group, N.u64p(row), N.u8p(buf)))
-            out += buf.tobytes()
-        return bytes(out)
+        return points.to_bytes()
     return b"".join(bytes(p.to_bytes()) for p in points)
 
 
@@ -35,7 +28,10 @@ def _block(points):
 
 
 def _read_points(E, data, count, width):
-    return [E.from_hex(data[i * width:(i + 1) * width].hex()) for i in range(count)]
+    """`count` points of `width` bytes (G1: the curve's point size, G2: twice that) as a PointArray"""
+    n = CurvePointSize[E.name].value
+    assert len(data) >= count * width, "Invalid key length"
+    return PointArray.from_compressed(E.curve_id, 1 if width == n else 2, data, count)
 
 
 class Proof:

@@ -106,7 +106,8 @@ class ProvingKey:
         view = memoryview(s)
         count = int.from_bytes(view[:8], "little")
         off = 8
-        tau_g1 = [E.from_hex(bytes(view[off + i * n: off + (i + 1) * n]).hex()) for i in range(count)]
+        assert len(s) >= off + (count + 8) * n, "Invalid proving key length"
+        tau_g1 = PointArray.from_compressed(E.curve_id, 1, view[off:off + count * n], count)
         off += count * n
         commits = [E.from_hex(bytes(view[off + i * n: off + (i + 1) * n]).hex()) for i in range(8)]
         off += 8 * n
@@ -122,7 +123,7 @@ class ProvingKey:
 
     def to_bytes(self) -> bytes:
         out = [len(self.tau_g1).to_bytes(8, "little")]
-        out += [bytes(t.to_bytes()) for t in self.tau_g1]
+        out.append(self.tau_g1.to_bytes() if isinstance(self.tau_g1, PointArray) else b"".join(bytes(t.to_bytes()) for t in self.tau_g1))
         out += [bytes(self.tau_selector_poly[k].to_bytes()) for k in SELECTORS]
         out += [bytes(p.to_bytes()) for p in self.tau_permutation_poly]
         for arr in [self._selector[k] for k in SELECTORS] + self._permutation + self._identity:
