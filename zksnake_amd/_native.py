@@ -49,6 +49,8 @@ SIGNATURES = {
     "zk_dev_alloc": (_i, [_u64, ctypes.POINTER(_vp)]),
     "zk_dev_free": (_i, [_vp]),
     "zk_dev_upload": (_i, [_vp, _vp, _u64]),
+    "zk_host_alloc": (_i, [_u64, ctypes.POINTER(_vp)]),
+    "zk_host_free": (_i, [_vp]),
     "zk_dev_download": (_i, [_vp, _vp, _u64]),
     "zk_dev_memset": (_i, [_vp, _i, _u64]),
     "zk_dev_synchronize": (_i, []),
@@ -200,14 +202,18 @@ except ImportError:  # pragma: no cover - e.g. a different interpreter than the 
     _pyints = None
 
 
-def ints_to_limbs(vals, words=4, modulus=None):
+def ints_to_limbs(vals, words=4, modulus=None, out=None):
     """list of non-negative ints -> (n, words) uint64, little-endian limbs.  Negative ints raise
     OverflowError, as pyo3's BigUint extraction does in the reference; with `modulus` values are
-    reduced first, which is what `Fr::from(BigUint)` does (src/bn254/curve.rs:359)."""
+    reduced first, which is what `Fr::from(BigUint)` does (src/bn254/curve.rs:359).
+    `out`: a C-contiguous (n, words) uint64 array to fill (a reused / page-locked staging buffer)."""
+    if out is not None:
+        assert out.dtype == np.uint64 and out.flags.c_contiguous and out.shape == (len(vals), words)
     if _pyints is not None:
         if not isinstance(vals, (list, tuple)):
             vals = list(vals)
-        out = np.empty((len(vals), words), dtype=np.uint64)
+        if out is None:
+            out = np.empty((len(vals), words), dtype=np.uint64)
         _pyints.ints_to_limbs(vals, words, modulus, out)
         return out
     nbytes = 8 * words
@@ -219,7 +225,11 @@ def ints_to_limbs(vals, words=4, modulus=None):
         if modulus is not None and v >= modulus:
             v %= modulus
         chunks.append(v.to_bytes(nbytes, "little"))
-    return np.frombuffer(b"".join(chunks), dtype=np.uint64).reshape(len(vals), words).copy()
+    arr = np.frombuffer(b"".join(chunks), dtype=np.uint64).reshape(len(vals), words)
+    if out is None:
+        return arr.copy()
+    out[:] = arr
+    return out
 
 
 def limbs_to_ints(arr):

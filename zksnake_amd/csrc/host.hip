@@ -378,6 +378,14 @@ int zk_dev_memset(void* d_dst, int value, uint64_t bytes) {
     if (bytes) ZK_HIP(hipMemset(d_dst, value, bytes));
     return ZK_OK;
 }
+int zk_host_alloc(uint64_t bytes, void** h_ptr) {
+    ZK_HIP(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return ZK_OK;
+}
+int zk_host_free(void* h_ptr) {
+    if (h_ptr) ZK_HIP(hipHostFree(h_ptr));
+    return ZK_OK;
+}
 int zk_dev_synchronize(void) {
     ZK_HIP(hipDeviceSynchronize());
     return ZK_OK;

@@ -841,7 +841,6 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ buckets) {
     typedef typename G::F F;
     constexpr int AW = 2 * F::LIMBS;
-    constexpr int XW = 4 * F::LIMBS;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = bucket_start[n_keys];
     const uint32_t begin = t * seg_len;

@@ -2,13 +2,16 @@
  *
  * The reference marshals every scalar through pyo3's BigUint extraction (`Fr::from(BigUint)`, src/bn254/curve.rs:358-361;
  * negative ints raise OverflowError there).  The reference-shaped API of this package (prove(list[int], list[int])) has to
- * do the same for 2^20 and more witness values per call; `int.to_bytes` per element costs ~180 ms at 2^20, this loop ~40.
+ * do the same for 2^20 and more witness values per call; `int.to_bytes` per element costs ~180 ms at 2^20, one thread of this loop ~45, eight ~8.
  * Pure marshalling: no field arithmetic happens here (values >= the modulus take the Python-level `%`).
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
+#include <pthread.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 /* value of a non-negative PyLong into `words` little-endian 64-bit limbs, straight from its 30-bit digits (CPython 3.8 .. 3.11
  * layout; anything else goes through _PyLong_AsByteArray).  Returns 0 ok, 1 does not fit, -1 not applicable. */
@@ -42,6 +45,64 @@ static int pack_digits(PyObject* v, unsigned char* dst, size_t words) {
 #endif
 }
 
+/* ---- the bulk of a witness: exact, non-negative ints that fit and are below the modulus -------------------------------
+ * Worker threads repack those straight from the digits while the calling thread keeps the GIL (so nothing can mutate the
+ * sequence or its ints meanwhile; the workers only read, they touch no reference count).  Everything else -- other
+ * types, negative or oversized values, values >= the modulus -- is flagged and handled afterwards in index order by the
+ * general path below, so the first offending element still decides the exception. */
+typedef struct {
+    PyObject** items;
+    Py_ssize_t begin, end;
+    size_t words;
+    unsigned char* dst;
+    const uint64_t* mod;   /* NULL = no modulus */
+    unsigned char* slow;   /* per element: 1 = leave to the general path */
+} PackJob;
+
+static void* pack_worker(void* arg) {
+    PackJob* job = (PackJob*)arg;
+    const size_t nbytes = job->words * 8;
+    for (Py_ssize_t i = job->begin; i < job->end; ++i) {
+        if (i + 8 < job->end) __builtin_prefetch(job->items[i + 8]);
+        PyObject* item = job->items[i];
+        unsigned char* p = job->dst + (size_t)i * nbytes;
+        int ok = PyLong_CheckExact(item) && pack_digits(item, p, job->words) == 0;
+        if (ok && job->mod) {
+            uint64_t v[16];
+            memcpy(v, p, nbytes);
+            int cmp = 0;
+            for (Py_ssize_t k = (Py_ssize_t)job->words - 1; k >= 0 && cmp == 0; --k) cmp = v[k] > job->mod[k] ? 1 : (v[k] < job->mod[k] ? -1 : 0);
+            ok = cmp < 0;
+        }
+        job->slow[i] = (unsigned char)!ok;
+    }
+    return NULL;
+}
+
+#define PACK_MAX_THREADS 8
+#define PACK_PARALLEL_MIN 16384
+
+static void pack_fast(PyObject** items, Py_ssize_t n, size_t words, unsigned char* dst, const uint64_t* mod, unsigned char* slow) {
+    long cores = sysconf(_SC_NPROCESSORS_ONLN);
+    int threads = n >= PACK_PARALLEL_MIN ? (int)(cores > PACK_MAX_THREADS ? PACK_MAX_THREADS : (cores < 1 ? 1 : cores)) : 1;
+    PackJob jobs[PACK_MAX_THREADS];
+    pthread_t tids[PACK_MAX_THREADS];
+    int started[PACK_MAX_THREADS];
+    const Py_ssize_t chunk = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; ++t) {
+        Py_ssize_t b = t * chunk, e = b + chunk > n ? n : b + chunk;
+        if (b > n) b = n;
+        jobs[t] = (PackJob){items, b, e, words, dst, mod, slow};
+        started[t] = 0;
+        if (t > 0) started[t] = pthread_create(&tids[t], NULL, pack_worker, &jobs[t]) == 0;
+    }
+    pack_worker(&jobs[0]);
+    for (int t = 1; t < threads; ++t) {
+        if (started[t]) pthread_join(tids[t], NULL);
+        else pack_worker(&jobs[t]);
+    }
+}
+
 /* ints_to_limbs(seq, words, modulus_or_None, out) -> None.  out: writable buffer of len(seq) * words * 8 bytes. */
 static PyObject* ints_to_limbs(PyObject* self, PyObject* args) {
     PyObject *seq, *modulus;
@@ -54,14 +115,21 @@ static PyObject* ints_to_limbs(PyObject* self, PyObject* args) {
     const size_t nbytes = (size_t)words * 8;
     unsigned char* dst = (unsigned char*)out.buf;
     unsigned char mod_bytes[128];
+    uint64_t mod_words[16];
     int have_mod = modulus != Py_None;
     PyObject* result = NULL;
-    if ((size_t)out.len < (size_t)n * nbytes || nbytes > sizeof(mod_bytes)) {
+    unsigned char* slow = NULL;
+    if ((size_t)out.len < (size_t)n * nbytes || nbytes > sizeof(mod_bytes) || words < 1) {
         PyErr_SetString(PyExc_ValueError, "output buffer too small");
         goto done;
     }
     if (have_mod && _PyLong_AsByteArray((PyLongObject*)modulus, mod_bytes, nbytes, 1, 0) < 0) goto done;
+    slow = (unsigned char*)malloc(n > 0 ? (size_t)n : 1);
+    if (!slow) { PyErr_NoMemory(); goto done; }
+    memcpy(mod_words, mod_bytes, have_mod ? nbytes : 0);
+    pack_fast(PySequence_Fast_ITEMS(fast), n, (size_t)words, dst, have_mod ? mod_words : NULL, slow);
     for (Py_ssize_t i = 0; i < n; ++i) {
+        if (!slow[i]) continue;
         PyObject* item = PySequence_Fast_GET_ITEM(fast, i);
         PyObject* v = PyNumber_Index(item);  /* accepts numpy integers too; new reference */
         if (!v) goto done;
@@ -102,6 +170,7 @@ static PyObject* ints_to_limbs(PyObject* self, PyObject* args) {
     Py_INCREF(Py_None);
     result = Py_None;
 done:
+    free(slow);
     Py_DECREF(fast);
     PyBuffer_Release(&out);
     return result;

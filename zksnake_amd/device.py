@@ -46,3 +46,28 @@ class DeviceBuffer:
             self.free()
         except Exception:  # noqa: BLE001
             pass
+
+
+class PinnedArray:
+    """page-locked host memory viewed as a numpy array (`.array`): staging for vectors that cross the link every proof"""
+
+    def __init__(self, shape, dtype=np.uint64):
+        lib = N.ensure_gpu()
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = ctypes.c_void_p()
+        N.check(lib.zk_host_alloc(self.nbytes, ctypes.byref(ptr)))
+        self.ptr = ptr.value
+        raw = (ctypes.c_uint8 * max(1, self.nbytes)).from_address(self.ptr)
+        self.array = np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            N.load().zk_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass

@@ -242,12 +242,9 @@ class Groth16:
                 dist.broadcast_object_list(box, src=0)
                 r, s = box[0]
 
-        if isinstance(public_witness, np.ndarray) or isinstance(private_witness, np.ndarray):
-            pub = public_witness if isinstance(public_witness, np.ndarray) else N.ints_to_limbs(public_witness, 4, q)
-            prv = private_witness if isinstance(private_witness, np.ndarray) else N.ints_to_limbs(private_witness, 4, q)
-            witness = (pub, prv)
-        else:
-            witness = list(public_witness) + list(private_witness)
+        # limb arrays go up as they are; lists of ints (the reference's call shape) are repacked by the QAP straight into its
+        # page-locked staging rows -- no concatenated copy of the two lists, no fresh 32 MB array per proof
+        witness = tuple(x if isinstance(x, (np.ndarray, list, tuple)) else list(x) for x in (public_witness, private_witness))
         n_pub = self.qap.n_public
         n_priv = len(private_witness)
         early = {}

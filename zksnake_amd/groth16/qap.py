@@ -13,7 +13,7 @@ import numpy as np
 
 from .. import _native as N
 from ..constant import BN254_SCALAR_FIELD
-from ..device import DeviceBuffer
+from ..device import DeviceBuffer, PinnedArray
 from ..polynomial import POLY_OBJECT
 from ..utils import next_power_of_two
 
@@ -67,7 +67,8 @@ class QAP:
         if self._ws is None or self._ws[0] != key:
             eb = 32
             self._ws = (key, dict(w=DeviceBuffer(n_col * eb), a=DeviceBuffer(n * eb), b=DeviceBuffer(n * eb),
-                                  c=DeviceBuffer(n * eb), h=DeviceBuffer(n * eb), work=DeviceBuffer(4 * n * eb)))
+                                  c=DeviceBuffer(n * eb), h=DeviceBuffer(n * eb), work=DeviceBuffer(4 * n * eb),
+                                  w_host=PinnedArray((n_col, 4))))
         return self._ws[1]
 
     def _qap_stream(self):
@@ -92,22 +93,21 @@ class QAP:
         log_n = n.bit_length() - 1
         # the witness may come as ints, as one limb array, or as (public, private) limb arrays (uploaded piecewise:
         # concatenating 2^20 x 32 B on the host would cost more than the upload itself)
-        if isinstance(witness, tuple):
-            parts = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in witness]
-        elif isinstance(witness, np.ndarray):
-            parts = [witness]
-        else:
-            parts = [N.ints_to_limbs(witness, 4, self.p)]
-        if sum(p.shape[0] for p in parts) != self.a.n_col:
+        parts = list(witness) if isinstance(witness, tuple) else [witness]
+        parts = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) if isinstance(p, np.ndarray) else p for p in parts]
+        if sum(len(p) for p in parts) != self.a.n_col:
             raise ValueError("witness length does not match the number of R1CS columns")
         ws = self._workspace(n, self.a.n_col)
         st = self._qap_stream()
-        off = 0
+        row = 0
         for part in parts:
-            if part.shape[0]:
-                ws["w"].upload(part, offset=off)
-            off += part.nbytes
-        if any(isinstance(x, np.ndarray) for x in (witness if isinstance(witness, tuple) else (witness,))):
+            if len(part) and not isinstance(part, np.ndarray):
+                # ints (the reference's call shape) are repacked into the page-locked staging rows, reduced mod r
+                part = N.ints_to_limbs(part, 4, self.p, out=ws["w_host"].array[row:row + len(part)])
+            if len(part):
+                ws["w"].upload(part, offset=32 * row)
+            row += len(part)
+        if any(isinstance(p, np.ndarray) for p in (witness if isinstance(witness, tuple) else (witness,))):
             # int lists were reduced mod r on the host (Fr::from); limb arrays are reduced here, one cheap pass
             N.check(lib.zk_vec_canon_dev(cid, self.a.n_col, ws["w"].ptr, st))
             N.check(lib.zk_stream_synchronize(st))
