@@ -103,6 +103,8 @@ def main():
     N.check(lib.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, N.MSM_PRECOMPUTE if args.precompute else 0, args.window_bits, handle))
     c_bits, nwin = N._i(0), N._i(0)
     N.check(lib.zk_msm_plan_windows(handle, c_bits, nwin))
+    entries = N._u64(0)
+    N.check(lib.zk_msm_plan_entries(handle, entries))   # per window: 2n when the plan runs on endomorphism pairs
     ranges = window_ranges(nwin.value, world)
     w_first, w_count = ranges[rank]
 
@@ -185,6 +187,8 @@ def main():
                 "log_n": args.log_n,
                 "window_bits": c_bits.value,
                 "windows": nwin.value,
+                "entries_per_window": entries.value,
+                "endomorphism_split": bool(entries.value == 2 * n),
                 "precompute": bool(args.precompute),
                 "parallelism": f"window-sharded x{world}" if world > 1 else "single GPU",
                 "collective_backend": (dist.get_backend() if world > 1 else None),
@@ -208,10 +212,11 @@ def main():
             "roofline_valu": {
                 "kernel": "accumulate_kernel<Bn254G1>",
                 "bound": "int32 multiply-add issue (v_mad_u64_u32)",
-                "achieved": round(nwin.value * n * MADS_PER_MIXED_ADD / acc_s / 1e12, 3) if acc_s > 0 and world == 1 else None,
+                "achieved": round(nwin.value * entries.value * MADS_PER_MIXED_ADD / acc_s / 1e12, 3) if acc_s > 0 and world == 1 else None,
                 "peak": 26.4,
                 "unit": "Tmad/s",
-                "frac": round(nwin.value * n * MADS_PER_MIXED_ADD / acc_s / 1e12 / 26.4, 4) if acc_s > 0 and world == 1 else None,
+                "frac": round(nwin.value * entries.value * MADS_PER_MIXED_ADD / acc_s / 1e12 / 26.4, 4) if acc_s > 0 and world == 1 else None,
+                "mixed_additions_per_launch": nwin.value * entries.value,
             },
             "stage_ms": {
                 "digits_sort": round(float(stage[0]), 4),
@@ -465,6 +470,8 @@ def group_msm_metrics(lib, torch):
         del bases
         nw, cb = N._i(0), N._i(0)
         N.check(lib.zk_msm_plan_windows(h, cb, nw))
+        ent = N._u64(0)
+        N.check(lib.zk_msm_plan_entries(h, ent))
         res = np.zeros(PW, dtype=np.uint64)
         tm = (N.ctypes.c_float * 5)()
         for _ in range(2):
@@ -481,7 +488,7 @@ def group_msm_metrics(lib, torch):
         ms = float(np.median(walls))
         st = np.array(stages).mean(axis=0)
         acc_s = float(st[1]) * 1e-3
-        mads = nw.value * n * mads_per_mixed_add(cid, grp)
+        mads = nw.value * ent.value * mads_per_mixed_add(cid, grp)
         out[f"msm_{key}_2^20"] = {
             "ms": round(ms, 4), "Mscalar/s": round(n / ms / 1e3, 2),
             "stage_ms": {"digits_sort": round(float(st[0]), 4), "accumulate": round(float(st[1]), 4), "reduce": round(float(st[2]), 4),

@@ -144,6 +144,11 @@ int zk_batch_mul(int curve, int group, uint64_t n, const uint64_t* scalars, cons
  * shares one bucket set (uses n * windows * point bytes of HBM); window_bits 0 = automatic. */
 #define ZK_MSM_PRECOMPUTE 1
 #define ZK_MSM_HIGH_PRIORITY 2 /* the plan's own stream (ZK_STREAM_PLAN) gets the top stream priority */
+/* General (not ZK_MSM_PRECOMPUTE) G1 plans of up to 2^22 points split every scalar with the curve's endomorphism,
+ * k = k1 + lambda k2 with |k1|, |k2| < 2^127, and run over the 2n points (P_i, (beta x_i, y_i)): the same number of bucket
+ * additions in half the windows, so half the bucket sets to reduce and half the doublings in the tail.  The result is the
+ * same point.  This flag (or ZKMI_NO_GLV=1 in the environment) keeps the plain 254/255-bit windows. */
+#define ZK_MSM_NO_GLV 4
 int zk_msm_plan_create(int curve, int group, uint64_t n, const void* bases, int bases_on_device, int flags,
                        int window_bits, uint64_t* handle);
 /* The same for a rank of a window-sharded MSM that will only ever run the windows
@@ -174,13 +179,16 @@ int zk_msm_plan_enqueue(uint64_t handle, uint64_t n_scalars, const void* scalars
                         int window_first, int window_count, void* stream);
 /* The same scalars against a second set of bases (Groth16: <tau_1, v> in G1 and <tau_2, v> in G2): run `handle` on the
  * digits and the sorted entry list of `lender_handle`'s run in flight instead of sorting again.  Both plans must have the
- * same size, window layout, mode and window range (else ZK_ERR_ARG: enqueue normally); finish both as usual. */
+ * same size, window layout, mode and window range (else ZK_ERR_ARG: enqueue normally); finish both as usual.  A general-mode
+ * G1 lender must have been created with ZK_MSM_NO_GLV (a split-scalar sort is of no use to a G2 plan). */
 int zk_msm_plan_enqueue_shared(uint64_t handle, uint64_t lender_handle, void* stream);
 int zk_msm_plan_finish(uint64_t handle, uint64_t* out);
 int zk_msm_plan_windows(uint64_t handle, int* window_bits, int* n_windows);
 /* the window width and count a plan over n points will use (window_bits 0 = automatic), without creating one: what a
  * rank needs to pick its share before zk_msm_plan_create_range */
-int zk_msm_window_layout(int curve, uint64_t n, int window_bits, int* window_bits_out, int* n_windows);
+int zk_msm_window_layout(int curve, int group, uint64_t n, int flags, int window_bits, int* window_bits_out, int* n_windows);
+/* entries one window of the plan sorts and accumulates: n, or 2n when the plan runs on endomorphism pairs */
+int zk_msm_plan_entries(uint64_t handle, uint64_t* entries_per_window);
 /* milliseconds of the stages of the last zk_msm_plan_run on this plan, measured with HIP events on
  * the launch stream(s): [0] digits+sort, [1] bucket accumulation (dominant kernel; summed over its launches),
  * [2] bucket combination + reduction + D2H, [3] host tail, [4] total.  Returns the number of floats written. */

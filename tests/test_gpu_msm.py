@@ -65,28 +65,38 @@ def test_msm_length_rules(gpu):
     assert gpu.zk_msm(7, 1, 1, 1, N.u64p(sc), N.u64p(bases), N.u64p(out)) == N.ZK_ERR_ARG
 
 
+@pytest.mark.parametrize("flags", [0, N.MSM_NO_GLV])
+@pytest.mark.parametrize("name,cid", CURVES)
 @pytest.mark.parametrize("c", [4, 7, 11, 13, 16])
-def test_msm_window_sizes_and_sharding(gpu, c):
-    """every window width gives the same point; partial results of disjoint window ranges add up"""
-    cid, grp, cv = 0, 1, pyref.BN254
+def test_msm_window_sizes_and_sharding(gpu, name, cid, c, flags):
+    """every window width gives the same point, with the scalars split by the endomorphism (the default for general G1
+    plans: 2n entries in windows over 128 bits) and without; partial results of disjoint window ranges add up"""
+    grp, cv = 1, pyref.curve_by_name(name)
     n = 3000
     _, bases = oracle_bases(cid, grp, n, 70)
-    _, sc = rand_scalars(n, cv.r, 71)
+    vals, _ = rand_scalars(n, cv.r, 71)
+    vals[:6] = [0, 1, cv.r - 1, cv.r + 5, (1 << 256) - 1, cv.r // 2]   # reduced mod r like Fr::from(BigUint)
+    sc = N.ints_to_limbs(vals, 4)
     exp = corc.msm(cid, grp, sc, bases, threads=8)
     h = N._u64(0)
-    N.check(gpu.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, 0, c, h))
+    N.check(gpu.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, flags, c, h))
     try:
-        cb, nw = N._i(0), N._i(0)
+        cb, nw, ent = N._i(0), N._i(0), N._u64(0)
         N.check(gpu.zk_msm_plan_windows(h, cb, nw))
-        assert cb.value == c and nw.value * c >= 255
-        out = np.zeros(8, dtype=np.uint64)
+        N.check(gpu.zk_msm_plan_entries(h, ent))
+        assert ent.value == (n if flags else 2 * n)
+        assert cb.value == c and nw.value * c >= (cv.r.bit_length() + 1 if flags else 128) and (nw.value - 1) * c < (256 if flags else 128)
+        lc, ln = N._i(0), N._i(0)
+        N.check(gpu.zk_msm_window_layout(cid, grp, n, flags, c, lc, ln))
+        assert (lc.value, ln.value) == (cb.value, nw.value)
+        out = np.zeros(N.point_limbs(cid, grp), dtype=np.uint64)
         N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, 0, 0, N.u64p(out), None))
         assert (out == exp).all()
         from zksnake_amd.parallel import sum_points, window_ranges
         for world in (2, 3, 8):
             parts = []
             for first, count in window_ranges(nw.value, world):
-                part = np.zeros(8, dtype=np.uint64)
+                part = np.zeros(N.point_limbs(cid, grp), dtype=np.uint64)
                 if count:
                     N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, first, count, N.u64p(part), None))
                 parts.append(part)
@@ -196,7 +206,10 @@ def test_plan_for_a_window_range(gpu, flags):
     _, bases = oracle_bases(cid, grp, n, 95)
     _, sc = rand_scalars(n, cv.r, 96)
     exp = corc.msm(cid, grp, sc, bases, threads=8)
-    nwin = (254 + 1 + 12 - 1) // 12
+    lc, ln = N._i(0), N._i(0)
+    N.check(gpu.zk_msm_window_layout(cid, grp, n, flags, 12, lc, ln))   # what a rank asks before it creates its plan
+    nwin = ln.value
+    assert lc.value == 12 and nwin == ((254 + 1 + 12 - 1) // 12 if flags else (128 + 12 - 1) // 12)
     parts = []
     for first, count in window_ranges(nwin, 3):
         h = N._u64(0)
@@ -412,7 +425,7 @@ def test_fixed_base_plan_ragged_size_above_2_20(gpu):
         N.check(gpu.zk_msm_plan_destroy(h2))
 
 
-@pytest.mark.parametrize("flags,n", [(1, 5000), (0, 5000), (1, 1 << 20)])
+@pytest.mark.parametrize("flags,n", [(1, 5000), (N.MSM_NO_GLV, 5000), (1, 1 << 20)])
 def test_shared_sort_between_g1_and_g2_plans(gpu, flags, n):
     """zk_msm_plan_enqueue_shared: the G2 plan runs on the digits and the sorted entry list of the G1 plan's run in flight
     (Groth16's <tau_1, v> and <tau_2, v>); results equal the independently sorted runs, the lender can run again at once,
@@ -449,6 +462,16 @@ def test_shared_sort_between_g1_and_g2_plans(gpu, flags, n):
         N.check(gpu.zk_msm_plan_finish(plans[1], N.u64p(o1)))
         assert (o1 == singles[(1, "a")]).all()
         N.check(gpu.zk_msm_plan_destroy(hs))
+        if flags == N.MSM_NO_GLV:
+            # a general G1 plan that splits its scalars with the endomorphism sorts 2n half-scalars: nothing a G2 plan could use
+            bases1, _ = _bases_from_library(gpu, cid, 1, n, 0xC0FFEE + 1)
+            hg = N._u64(0)
+            N.check(gpu.zk_msm_plan_create(cid, 1, n, bases1.ctypes.data, 0, 0, 0, hg))
+            N.check(gpu.zk_msm_plan_enqueue(hg, n, sc.ctypes.data, 0, 0, 0, N.STREAM_PLAN))
+            assert gpu.zk_msm_plan_enqueue_shared(plans[2], hg, N.STREAM_PLAN) == N.ZK_ERR_ARG
+            N.check(gpu.zk_msm_plan_finish(hg, N.u64p(o1)))
+            assert (o1 == singles[(1, "a")]).all()
+            N.check(gpu.zk_msm_plan_destroy(hg))
     finally:
         for h in plans.values():
             N.check(gpu.zk_msm_plan_destroy(h))

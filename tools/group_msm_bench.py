@@ -61,6 +61,8 @@ def main():
         plan_s = time.perf_counter() - t0
         cb, nw = N._i(0), N._i(0)
         N.check(lib.zk_msm_plan_windows(h, cb, nw))
+        ent = N._u64(0)
+        N.check(lib.zk_msm_plan_entries(h, ent))
         res = np.zeros(PW, dtype=np.uint64)
         tm = (N.ctypes.c_float * 5)()
         for _ in range(2):
@@ -75,7 +77,7 @@ def main():
         ms = (time.perf_counter() - t0) / reps * 1e3
         st = np.array(stages).mean(axis=0)
         acc_s = st[1] * 1e-3
-        mads = nw.value * n * mads_per_mixed_add(cid, grp)
+        mads = nw.value * ent.value * mads_per_mixed_add(cid, grp)
         out_all[key] = {"curve": curve, "group": grp, "log_n": log_n, "precompute": bool(flags), "match": ok, "ms": round(ms, 4),
                         "Mscalar/s": round(n / ms / 1e3, 2), "window_bits": cb.value, "windows": nw.value, "plan_create_s": round(plan_s, 3),
                         "stage_ms": {"digits_sort": round(float(st[0]), 4), "accumulate": round(float(st[1]), 4),

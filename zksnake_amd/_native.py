@@ -31,6 +31,7 @@ G2 = 2
 
 MSM_PRECOMPUTE = 1
 MSM_HIGH_PRIORITY = 2
+MSM_NO_GLV = 4
 STREAM_PLAN = ctypes.c_void_p(-1)  # ZK_STREAM_PLAN: the plan's own stream
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -80,7 +81,8 @@ SIGNATURES = {
     "zk_msm_plan_enqueue_shared": (_i, [_u64, _u64, _vp]),
     "zk_msm_plan_finish": (_i, [_u64, _u64p]),
     "zk_msm_plan_windows": (_i, [_u64, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
-    "zk_msm_window_layout": (_i, [_i, _u64, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "zk_msm_window_layout": (_i, [_i, _i, _u64, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "zk_msm_plan_entries": (_i, [_u64, ctypes.POINTER(_u64)]),
     "zk_msm_plan_timings": (_i, [_u64, ctypes.POINTER(ctypes.c_float), _i]),
     "zk_point_add": (_i, [_i, _i, _u64p, _u64p, _u64p]),
     "zk_point_neg": (_i, [_i, _i, _u64p, _u64p]),

@@ -113,19 +113,15 @@ int zk_msm_plan_finish(uint64_t handle, uint64_t* out) {
     return p->finish(out);
 }
 
-int zk_msm_window_layout(int curve, uint64_t n, int window_bits, int* window_bits_out, int* n_windows) {
-    // the same rule as MsmPlan::init (msm_impl.cuh): c = 16 from 2^16 points on, log2(n) - 2 below (at least 4)
+int zk_msm_window_layout(int curve, int group, uint64_t n, int flags, int window_bits, int* window_bits_out, int* n_windows) {
+    // the same rule as MsmPlan::init (msm_plan.h: msm_layout), for a rank's share of a window-sharded MSM
     if (curve != ZK_CURVE_BN254 && curve != ZK_CURVE_BLS12_381) return fail(ZK_ERR_ARG, "unknown curve");
-    int c = window_bits;
-    if (c <= 0) {
-        int lg = log2_u64(n < 2 ? 2 : n);
-        c = lg >= 16 ? 16 : lg - 2;
-        if (c < 4) c = 4;
-    }
-    if (c < 2 || c > 20) return fail(ZK_ERR_ARG, "window bits must be in [2, 20]");
+    if (group != ZK_G1 && group != ZK_G2) return fail(ZK_ERR_ARG, "unknown group");
     const int bits = curve == ZK_CURVE_BN254 ? BnFrParams::BITS : BlsFrParams::BITS;
-    *window_bits_out = c;
-    *n_windows = (bits + 1 + c - 1) / c;
+    const MsmLayout lay = msm_layout(bits, group == ZK_G1, n, flags, window_bits, false);
+    if (lay.c < 2 || lay.c > 20) return fail(ZK_ERR_ARG, "window bits must be in [2, 20]");
+    *window_bits_out = lay.c;
+    *n_windows = lay.nwin;
     return ZK_OK;
 }
 
@@ -134,6 +130,13 @@ int zk_msm_plan_windows(uint64_t handle, int* window_bits, int* n_windows) {
     if (!p) return fail(ZK_ERR_ARG, "unknown MSM plan handle");
     *window_bits = p->c;
     *n_windows = p->nwin;
+    return ZK_OK;
+}
+
+int zk_msm_plan_entries(uint64_t handle, uint64_t* entries_per_window) {
+    MsmPlanBase* p = find_plan(handle);
+    if (!p) return fail(ZK_ERR_ARG, "unknown MSM plan handle");
+    *entries_per_window = p->entries_per_window;
     return ZK_OK;
 }
 

@@ -33,6 +33,7 @@
 #include "pair.cuh"
 #include "setup_impl.cuh"
 #include "codec.cuh"
+#include "glv_params.h"
 
 namespace zkmi {
 
@@ -122,6 +123,15 @@ __device__ __forceinline__ XYZZ<F> lds_get_xyzz(const uint32_t* slot) {
 constexpr uint32_t COMBINE_SMALL_MAX = 16;    // <= 16 runs: one lane adds them up
 constexpr uint32_t COMBINE_WAVE_MAX = 2048;   // <= 2048 runs: one wave per bucket; above: one workgroup
 
+
+// ---- G1 endomorphism (GLV) ---------------------------------------------------------------------------
+// General (not fixed-base) G1 plans run the MSM over 2n points (P_i, phi(P_i)) with the two ~127-bit halves of every
+// scalar, k = k1 + lambda k2: the same number of bucket additions (2n entries in half the windows), but half the bucket
+// sets to reduce and half the doublings in the host tail.  Constants and the decomposition: tools/gen_glv_params.py.
+template <class G> struct GlvOf { static constexpr bool OK = false; };
+template <> struct GlvOf<Bn254G1> { static constexpr bool OK = true; typedef Bn254Glv P; };
+template <> struct GlvOf<Bls381G1> { static constexpr bool OK = true; typedef Bls381Glv P; };
+
 #if !defined(ZK_PART) || ZK_PART == 0  // sort-stage kernels and the plan live in part 0 only
 // ---- 1. digits -----------------------------------------------------------------------------------
 
@@ -179,6 +189,108 @@ __global__ void digits_kernel(const uint32_t* __restrict__ scalars, uint32_t n, 
         if (word + 1 <= N) two |= (uint64_t)s[word + 1] << 32;
         uint32_t u = (uint32_t)(two >> off) & mask;
         dig[(size_t)w * dstride + i] = (DIG)u;  // rows padded to 8 digits: 16-byte aligned vector reads
+    }
+}
+
+// NA x NB words -> NA + NB words
+template <int NA, int NB>
+__device__ __forceinline__ void mul_words(uint32_t* out, const uint32_t* a, const uint32_t* b) {
+#pragma unroll
+    for (int k = 0; k < NA + NB; ++k) out[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        uint64_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const uint64_t t = (uint64_t)a[i] * b[j] + out[i + j] + carry;
+            out[i + j] = (uint32_t)t;
+            carry = t >> 32;
+        }
+        out[i + NB] = (uint32_t)carry;
+    }
+}
+// acc (4 words) -= a * b mod 2^128
+__device__ __forceinline__ void submul_lo4(uint32_t* acc, const uint32_t* a, const uint32_t* b) {
+    uint32_t p[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint64_t carry = 0;
+#pragma unroll
+        for (int j = 0; j + i < 4; ++j) {
+            const uint64_t t = (uint64_t)a[i] * b[j] + p[i + j] + carry;
+            p[i + j] = (uint32_t)t;
+            carry = t >> 32;
+        }
+    }
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const uint64_t t = (uint64_t)acc[l] - p[l] - borrow;
+        acc[l] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+}
+// (k g + 2^319) >> 320, four words
+__device__ __forceinline__ void glv_round_quotient(uint32_t* c, const uint32_t* k8, const uint32_t* g7) {
+    uint32_t prod[15];
+    mul_words<8, 7>(prod, k8, g7);
+    uint64_t carry = 0x80000000ull;  // 2^319 = bit 31 of word 9
+#pragma unroll
+    for (int l = 9; l < 15; ++l) {
+        const uint64_t t = (uint64_t)prod[l] + carry;
+        prod[l] = (uint32_t)t;
+        carry = t >> 32;
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) c[l] = prod[10 + l];
+}
+
+// digits of the two halves of every scalar: entry 2i carries k1 (against P_i), entry 2i + 1 carries k2 (against phi(P_i)).
+// The halves are signed; a signed value plus the bias is still a plain string of c-bit fields.
+template <class FrP>
+__global__ void glv_digits_kernel(const uint32_t* __restrict__ scalars, uint32_t m, uint32_t dstride, int c, int w_first, int w_count,
+                                  DigitBias bias, GlvConsts K, uint16_t* __restrict__ dig, uint32_t* __restrict__ big_count) {
+    constexpr int N = FrP::W;
+    static_assert(N == 8, "scalar fields of 8 words");
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) big_count[0] = big_count[1] = 0;
+    if (i >= m) return;
+    uint32_t s[N];
+    load_words<N>(s, scalars + (size_t)i * N);
+    for (int k = 0; k < 10; ++k) {
+        uint32_t t[N];
+        if (fp_sub_mod_raw<FrP>(t, s)) break;
+#pragma unroll
+        for (int l = 0; l < N; ++l) s[l] = t[l];
+    }
+    uint32_t c1[4], c2[4];
+    glv_round_quotient(c1, s, K.g1);
+    glv_round_quotient(c2, s, K.g2);
+    uint32_t k1[4] = {s[0], s[1], s[2], s[3]}, k2[4] = {0, 0, 0, 0};
+    submul_lo4(k1, c1, K.a1);
+    submul_lo4(k1, c2, K.a2);
+    submul_lo4(k2, c1, K.b1);
+    submul_lo4(k2, c2, K.b2);
+    uint32_t t1[6], t2[6];
+    {
+        const uint32_t e1 = (k1[3] >> 31) ? 0xFFFFFFFFu : 0u, e2 = (k2[3] >> 31) ? 0xFFFFFFFFu : 0u;
+        uint64_t ca = 0, cb = 0;
+#pragma unroll
+        for (int l = 0; l < 5; ++l) {
+            const uint64_t a = (uint64_t)(l < 4 ? k1[l] : e1) + bias.v[l] + ca;
+            const uint64_t b = (uint64_t)(l < 4 ? k2[l] : e2) + bias.v[l] + cb;
+            t1[l] = (uint32_t)a; ca = a >> 32;
+            t2[l] = (uint32_t)b; cb = b >> 32;
+        }
+        t1[5] = t2[5] = 0;
+    }
+    const uint32_t mask = (1u << c) - 1;
+    uint32_t* dig32 = reinterpret_cast<uint32_t*>(dig);
+    for (int w = w_first; w < w_first + w_count; ++w) {
+        const int bit = w * c, word = bit >> 5, off = bit & 31;
+        const uint32_t u1 = (uint32_t)((((uint64_t)t1[word + 1] << 32) | t1[word]) >> off) & mask;
+        const uint32_t u2 = (uint32_t)((((uint64_t)t2[word + 1] << 32) | t2[word]) >> off) & mask;
+        dig32[((size_t)w * dstride >> 1) + i] = u1 | (u2 << 16);
     }
 }
 
@@ -1042,8 +1154,9 @@ __global__ __launch_bounds__(HS_THREADS) void weighted_sum_kernel(const uint32_t
 
 // ---- bases: canonical -> Montgomery; batch scalar multiplication -------------------------------------
 
+// glv != 0: rows 2i = P_i and 2i + 1 = phi(P_i) = (beta x, y)
 template <class G>
-__global__ void bases_to_mont_kernel(const uint32_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ out) {
+__global__ void bases_to_mont_kernel(const uint32_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ out, int glv) {
     typedef typename G::F F;
     constexpr int AW = 2 * F::LIMBS;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1053,13 +1166,21 @@ __global__ void bases_to_mont_kernel(const uint32_t* __restrict__ in, uint64_t n
     Affine<F> p;
     p.x = F::from_canonical(w);
     p.y = F::from_canonical(w + F::LIMBS);
+    if constexpr (GlvOf<G>::OK) {
+        if (glv) {
+            store_affine<F>(out + 2 * i * AW, p);
+            p.x = F::mul(p.x, F::from_canonical(GlvOf<G>::P::BETA));
+            store_affine<F>(out + (2 * i + 1) * AW, p);
+            return;
+        }
+    }
     store_affine<F>(out + i * AW, p);
 }
 
 #if defined(ZK_GROUP) && (!defined(ZK_PART) || ZK_PART == 0)
 // the plan's translation unit does not instantiate the heavy kernels (see msm_group.hip)
 extern template __global__ void accumulate_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*);
-extern template __global__ void bases_to_mont_kernel<ZK_GROUP>(const uint32_t*, uint64_t, uint32_t*);
+extern template __global__ void bases_to_mont_kernel<ZK_GROUP>(const uint32_t*, uint64_t, uint32_t*, int);
 extern template __global__ void combine_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*);
 extern template __global__ void strided_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t*, SumJob, SumJob, uint32_t);
 extern template __global__ void weighted_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t, uint32_t, const uint32_t*, uint32_t, uint32_t*);
@@ -1069,16 +1190,6 @@ ZK_CODEC_EXTERN_TEMPLATES(ZK_GROUP)
 
 #if !defined(ZK_PART) || ZK_PART == 0
 // ---- host: plan --------------------------------------------------------------------------------------
-
-static int pick_window_bits(uint64_t n) {
-    // bucket sets must fit the LDS histogram (c <= 16) and stay well filled
-    // measured on MI355X (BN254 G1): 2^14 -> 12, 2^16..2^20 -> 16; the tail is latency-bound, so fewer
-    // windows win as soon as the buckets are reasonably filled
-    int lg = log2_u64(n < 2 ? 2 : n);
-    int c = lg >= 16 ? 16 : lg - 2;
-    if (c < 4) c = 4;
-    return c;
-}
 
 // ZK_MSM_PRECOMPUTE: table row k = 2^(c (w_first + k)) * P_i (affine, Montgomery) for the w_count windows of the plan; on
 // entry row 0 holds the bases themselves.  With these rows every window adds into ONE shared bucket set: the bucket
@@ -1181,7 +1292,6 @@ struct MsmPlan : MsmPlanBase {
     static constexpr int XW = 4 * F::LIMBS;
     static constexpr uint64_t SEG_TARGET_LANES = 256ull * 1024;  // 4 waves per SIMD on 256 CUs
     static constexpr int MAX_C = 20;           // widest window (fixed-base plans; digits are then 32-bit)
-    static constexpr int WIDE_C_DEFAULT = 20;  // measured at 2^20 BN254 G1: see DESIGN.md
     bool wide = false;                         // c > 16: 32-bit digits, two-level sort only
 
     // device workspace of one run (stages 2..7)
@@ -1198,7 +1308,9 @@ struct MsmPlan : MsmPlanBase {
         uint32_t groups = 0;           // bucket sets of the run in flight
     };
 
-    uint64_t n = 0;
+    uint64_t n = 0;      // entries per window (2 n_api with the endomorphism)
+    uint64_t n_api = 0;  // points of the plan as the caller counts them
+    bool glv = false;    // general G1 plan over (P_i, phi(P_i)) with half-length scalars
     bool pre = false;  // ZK_MSM_PRECOMPUTE: shared bucket set over a table of 2^(c w) P_i
     int pw_first = 0, pw_count = 0;  // windows this plan can run (a sharded rank's share; all of them by default)
     uint32_t B = 0, R = 0, C = 0;
@@ -1242,30 +1354,16 @@ struct MsmPlan : MsmPlanBase {
         create_flags = flags;
         pre = (flags & ZK_MSM_PRECOMPUTE) != 0;
         if (n_points == 0 || n_points > (1ull << 26)) return fail(ZK_ERR_ARG, "MSM size must be in [1, 2^26]");
-        n = n_points;
-        c = window_bits > 0 ? window_bits : pick_window_bits(n);
-        if (window_bits <= 0 && pre && win_count <= 0) {
-            // fixed-base plans over all windows: one shared bucket set makes wider windows affordable (13 windows of
-            // 20 bits instead of 16 of 16: 19 % fewer additions) as long as a table reference still fits the 32-bit
-            // sort entry.  Window-sharded plans keep 16 windows, which split evenly over 2, 4 or 8 ranks.
-            static const int pre_c = getenv("ZKMI_PRE_C") ? atoi(getenv("ZKMI_PRE_C")) : 0;
-            static const bool no_two_level = getenv("ZKMI_NO_TWO_LEVEL") != nullptr;  // wide windows exist in the two-level sort only
-            // Candidates whose TOP window is at least half full: all windows feed one bucket set, and a short top window
-            // (18 bits: 3 scalar bits left for it) would pile its n entries into a handful of buckets of one coarse bin.
-            const int cands[3] = {pre_c ? pre_c : WIDE_C_DEFAULT, 17, 0};
-            for (int k = 0; !no_two_level && cands[k] > 16; ++k) {
-                const int cand = cands[k];
-                const uint64_t w = (FrP::BITS + 1 + cand - 1) / cand;
-                const int top_bits = FrP::BITS + 1 - (int)(w - 1) * cand;
-                // below 2^20 points the wider bucket set costs more in the (latency-bound) reduction than the windows save
-                if (n >= (1ull << 20) && w < 16 && (2 * top_bits >= cand || pre_c) && w * n <= (1ull << (31 - (cand - 13)))) { c = cand; break; }
-                if (pre_c) break;
-            }
-        }
+        const MsmLayout lay = msm_layout(FrP::BITS, GlvOf<G>::OK, n_points, flags, window_bits, win_count <= 0);
+        glv = share ? share->glv : lay.glv;
+        n_api = n_points;
+        n = glv ? 2 * n_points : n_points;  // entries per window: the kernels see an MSM over (P_i, phi(P_i)) pairs
+        entries_per_window = n;
+        c = lay.c;
         if (c < 2 || c > MAX_C) return fail(ZK_ERR_ARG, "window bits must be in [2, 20]");
         if (c > 16 && !pre) return fail(ZK_ERR_ARG, "windows wider than 16 bits need a fixed-base plan (ZK_MSM_PRECOMPUTE)");
         wide = c > 16;
-        nwin = (FrP::BITS + 1 + c - 1) / c;
+        nwin = glv ? (GLV_BITS + c - 1) / c : (FrP::BITS + 1 + c - 1) / c;
         if (win_count <= 0) { win_first = 0; win_count = nwin; }
         if (win_first < 0 || win_first + win_count > nwin) return fail(ZK_ERR_ARG, "window range out of bounds");
         pw_first = win_first;
@@ -1300,14 +1398,14 @@ struct MsmPlan : MsmPlanBase {
             ZK_ALLOC(&bases_block->ptr, (pre ? (uint64_t)pw_count : 1ull) * n * AW * 4);
             d_bases = (uint32_t*)bases_block->ptr;
             if (bases_on_device) {
-                hipLaunchKernelGGL(bases_to_mont_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0,
-                                   (const uint32_t*)bases, n, d_bases);
+                hipLaunchKernelGGL(bases_to_mont_kernel<G>, dim3((unsigned)((n_api + 127) / 128)), dim3(128), 0, 0,
+                                   (const uint32_t*)bases, n_api, d_bases, glv ? 1 : 0);
             } else {
                 uint32_t* tmp = nullptr;
-                ZK_ALLOC(&tmp, n * AW * 4);
-                hipError_t e = hipMemcpy(tmp, bases, n * AW * 4, hipMemcpyHostToDevice);
+                ZK_ALLOC(&tmp, n_api * AW * 4);
+                hipError_t e = hipMemcpy(tmp, bases, n_api * AW * 4, hipMemcpyHostToDevice);
                 if (e == hipSuccess) {
-                    hipLaunchKernelGGL(bases_to_mont_kernel<G>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, tmp, n, d_bases);
+                    hipLaunchKernelGGL(bases_to_mont_kernel<G>, dim3((unsigned)((n_api + 127) / 128)), dim3(128), 0, 0, tmp, n_api, d_bases, glv ? 1 : 0);
                     e = hipDeviceSynchronize();
                 }
                 dev_free_cached(tmp);
@@ -1321,7 +1419,7 @@ struct MsmPlan : MsmPlanBase {
             }
         }
         mark("stream + bases");
-        ZK_ALLOC(&d_scalars, n * FrP::W * 4);
+        ZK_ALLOC(&d_scalars, n_api * FrP::W * 4);
         ZK_ALLOC(&d_dig, (size_t)pw_count * (n + 8) * (wide ? 4 : 2));
         if (wide && !two_level_ok()) return fail(ZK_ERR_ARG, "this size does not fit the two-level sort that wide windows need");
         const uint64_t max_sets = pre ? 1ull : (uint64_t)pw_count;
@@ -1404,10 +1502,18 @@ struct MsmPlan : MsmPlanBase {
             const int f = c - 13;  // 4096 coarse bins
             return refs <= (1ull << (31 - f)) ? f : 0;
         }
+        static const int f_env = getenv("ZKMI_FINE_LOG") ? atoi(getenv("ZKMI_FINE_LOG")) : 0;  // tuning knob (general mode)
+        if (f_env && !pre && refs <= (1ull << (31 - f_env)) && c - 1 >= f_env + 2 && sets * (B >> f_env) <= 4096) return f_env;
         const int f_hi = pre ? 5 : FINE_LOG_MAX, f_lo = pre ? 4 : FINE_LOG_MAX - 1;
-        for (int f = f_hi; f >= f_lo; --f)
-            if (refs <= (1ull << (31 - f)) && c - 1 >= f + 2 && sets * (B >> f) <= 4096) return f;
-        return 0;
+        // general mode: the widest bins that still hold about 8192 entries each (one level-B workgroup sorts a bin in LDS;
+        // 2^21 split-scalar entries per window: 7 fine bits, 0.175 ms for digits + sort against 0.20 with 8)
+        int best = 0;
+        for (int f = f_hi; f >= f_lo; --f) {
+            if (!(refs <= (1ull << (31 - f)) && c - 1 >= f + 2 && sets * (B >> f) <= 4096)) continue;
+            if (pre || (points >> (c - 1 - f)) <= 8192) return f;
+            best = f;
+        }
+        return best;
     }
 
     bool two_level_ok() const {
@@ -1526,7 +1632,7 @@ struct MsmPlan : MsmPlanBase {
         // lanes per output (two lanes = one point): many outputs (one bucket set per window) -> 16 pairs each walk
         // count/16 buckets and finish with a 4-level tree; few outputs (shared bucket set) -> 32 pairs, shortest chain
         static const uint32_t lpo_env = getenv("ZKMI_LPO") ? (uint32_t)atoi(getenv("ZKMI_LPO")) : 0u;
-        const uint32_t lpo = lpo_env ? lpo_env : ((n_rows + n_cols) >= 2048 ? 32u : 64u);
+        const uint32_t lpo = lpo_env ? lpo_env : ((n_rows + n_cols) >= 4096 ? 32u : 64u);
         hipLaunchKernelGGL(strided_sum_kernel<G>, dim3(((n_rows + n_cols) * lpo + 255) / 256), dim3(256), 0, st, l.buckets, l.rows, rows, cols, lpo);
         hipLaunchKernelGGL(weighted_sum_kernel<G>, dim3(groups * (bpr + bpc)), dim3(HS_THREADS), (size_t)HalfRegs<F>::COUNT * HS_THREADS * 4, st,
                            l.rows, R, groups, l.rows + (size_t)n_rows * XW, C, l.fin);
@@ -1539,7 +1645,7 @@ struct MsmPlan : MsmPlanBase {
     int create_flags = 0;
     int clone(MsmPlanBase** out) override {
         MsmPlan* p = new MsmPlan();
-        int rc = p->init(n, nullptr, 0, create_flags & ~ZK_MSM_HIGH_PRIORITY, c, pw_first, pw_count, this);
+        int rc = p->init(n_api, nullptr, 0, create_flags & ~ZK_MSM_HIGH_PRIORITY, c, pw_first, pw_count, this);
         if (rc) {
             delete p;
             return rc;
@@ -1557,12 +1663,13 @@ struct MsmPlan : MsmPlanBase {
     int enqueue(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count, hipStream_t st) override {
         std::lock_guard<std::mutex> lock(mu);
         if (q_pending) return fail(ZK_ERR_ARG, "MSM plan already has a run in flight: call zk_msm_plan_finish first");
-        if (n_scalars > n) return fail(ZK_ERR_LENGTH, "Number of points and scalars mismatch");
+        if (n_scalars > n_api) return fail(ZK_ERR_LENGTH, "Number of points and scalars mismatch");
         if (w_count <= 0) { w_first = pw_first; w_count = pw_count; }
         if (w_first < pw_first || w_first + w_count > pw_first + pw_count)
             return fail(ZK_ERR_ARG, "window range out of bounds (the plan was created for windows [" + std::to_string(pw_first) + ", " +
                                         std::to_string(pw_first + pw_count) + "))");
-        const uint32_t m = (uint32_t)n_scalars;
+        const uint32_t m_api = (uint32_t)n_scalars;
+        const uint32_t m = glv ? 2 * m_api : m_api;  // entries per window
         q_first = w_first; q_count = w_count; q_m = m; q_stream = st;
         if (ws.lent) {  // a borrower of the previous run's sort may still be reading the buffers this run overwrites
             ZK_HIP(hipStreamWaitEvent(st, ws.ev_release, 0));
@@ -1571,7 +1678,7 @@ struct MsmPlan : MsmPlanBase {
         if (m > 0) {
             const uint32_t* sc = (const uint32_t*)scalars;
             if (!on_device) {
-                ZK_HIP(hipMemcpyAsync(d_scalars, scalars, (size_t)m * FrP::W * 4, hipMemcpyHostToDevice, st));
+                ZK_HIP(hipMemcpyAsync(d_scalars, scalars, (size_t)m_api * FrP::W * 4, hipMemcpyHostToDevice, st));
                 sc = d_scalars;
             }
             const uint32_t dstride = (m + 7u) & ~7u;
@@ -1584,7 +1691,11 @@ struct MsmPlan : MsmPlanBase {
                 bias.v[bit >> 5] |= 1u << (bit & 31);
             }
             const uintptr_t dig_base = reinterpret_cast<uintptr_t>(d_dig) - (uintptr_t)pw_first * dstride * (wide ? 4 : 2);
-            if (wide) hipLaunchKernelGGL((digits_kernel<FrP, uint32_t>), dim3((m + 255) / 256), dim3(256), 0, st, sc, m, dstride, c, w_first, w_count, bias,
+            if (glv) {
+                if constexpr (GlvOf<G>::OK)
+                    hipLaunchKernelGGL(glv_digits_kernel<FrP>, dim3((m_api + 255) / 256), dim3(256), 0, st, sc, m_api, dstride, c, w_first, w_count, bias,
+                                       GlvOf<G>::P::K, reinterpret_cast<uint16_t*>(dig_base), ws.big_count);
+            } else if (wide) hipLaunchKernelGGL((digits_kernel<FrP, uint32_t>), dim3((m + 255) / 256), dim3(256), 0, st, sc, m, dstride, c, w_first, w_count, bias,
                                          reinterpret_cast<uint32_t*>(dig_base), ws.big_count);
             else hipLaunchKernelGGL((digits_kernel<FrP, uint16_t>), dim3((m + 255) / 256), dim3(256), 0, st, sc, m, dstride, c, w_first, w_count, bias,
                                     reinterpret_cast<uint16_t*>(dig_base), ws.big_count);
@@ -1607,7 +1718,7 @@ struct MsmPlan : MsmPlanBase {
         out->big_list = ws.big_list; out->big_count = ws.big_count;
         out->n = n; out->m = q_m; out->seg_len = ws.seg_len; out->groups = ws.groups;
         out->c = c; out->nwin = nwin; out->w_first = q_first; out->w_count = q_count;
-        out->pw_first = pw_first; out->pw_count = pw_count; out->scalar_bits = FrP::BITS; out->pre = pre;
+        out->pw_first = pw_first; out->pw_count = pw_count; out->scalar_bits = FrP::BITS; out->pre = pre; out->glv = glv;
         out->sorted_ready = ws.ev_acc0;
         out->release = ws.ev_release;
         ws.lent = true;
@@ -1623,8 +1734,8 @@ struct MsmPlan : MsmPlanBase {
         if (rc) return rc;
         std::lock_guard<std::mutex> lock(mu);
         if (q_pending) return fail(ZK_ERR_ARG, "MSM plan already has a run in flight: call zk_msm_plan_finish first");
-        if (ex.n != n || ex.c != c || ex.nwin != nwin || ex.pre != pre || ex.scalar_bits != FrP::BITS || ex.pw_first != pw_first ||
-            ex.pw_count != pw_count)
+        if (ex.n != n || ex.c != c || ex.nwin != nwin || ex.pre != pre || ex.glv != glv || ex.scalar_bits != FrP::BITS ||
+            ex.pw_first != pw_first || ex.pw_count != pw_count)
             return fail(ZK_ERR_ARG, "plans differ in size, window layout or mode: the sort cannot be shared");
         if (ws.lent) {
             ZK_HIP(hipStreamWaitEvent(st, ws.ev_release, 0));

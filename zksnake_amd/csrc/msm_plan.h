@@ -2,8 +2,10 @@
 // (msm_group.hip compiled once per curve group, so the four instantiations build in parallel).
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <mutex>
 #include <hip/hip_runtime.h>
+#include "../../include/zkmi.h"
 
 namespace zkmi {
 
@@ -21,10 +23,69 @@ struct SortExport {
     uint64_t n = 0;
     uint32_t m = 0, seg_len = 0, groups = 0;
     int c = 0, nwin = 0, w_first = 0, w_count = 0, pw_first = 0, pw_count = 0, scalar_bits = 0;
-    bool pre = false;
+    bool pre = false, glv = false;
     hipEvent_t sorted_ready = nullptr;  // recorded on the lender's stream after its sort stage
     hipEvent_t release = nullptr;       // the borrower records it after its last read; the lender's next run waits for it
 };
+
+// ---- window layout of a plan (shared by MsmPlan::init and zk_msm_window_layout) -----------------------------------
+constexpr int GLV_BITS = 128;                    // k + bias must fit nwin * c >= GLV_BITS bits (|k1|, |k2| < 2^127 - 2^112)
+constexpr uint64_t GLV_MAX_POINTS = 1ull << 22;  // 2n entries per window must leave the two-level sort its 8 fine bits
+constexpr int MSM_WIDE_C_DEFAULT = 20;           // fixed-base plans over all windows: measured at 2^20 BN254 G1, see DESIGN.md
+
+inline int msm_log2(uint64_t v) {
+    int l = 0;
+    while (v >>= 1) ++l;
+    return l;
+}
+
+inline int pick_window_bits(uint64_t entries) {
+    // bucket sets must fit the LDS histogram (c <= 16) and stay well filled
+    // measured on MI355X (BN254 G1): 2^14 -> 12, 2^16..2^20 -> 16; the tail is latency-bound, so fewer
+    // windows win as soon as the buckets are reasonably filled
+    int lg = msm_log2(entries < 2 ? 2 : entries);
+    int c = lg >= 16 ? 16 : lg - 2;
+    if (c < 4) c = 4;
+    return c;
+}
+
+struct MsmLayout {
+    int c = 0, nwin = 0;
+    bool glv = false;
+    uint64_t entries = 0;  // per window
+};
+
+// scalar_bits = bit length of r; has_glv = the group has the (beta x, y) endomorphism wired up (G1);
+// all_windows = the plan covers every window (not a rank's share of a window-sharded MSM)
+inline MsmLayout msm_layout(int scalar_bits, bool has_glv, uint64_t n_points, int flags, int window_bits, bool all_windows) {
+    MsmLayout L;
+    const bool pre = (flags & ZK_MSM_PRECOMPUTE) != 0;
+    static const bool no_glv = getenv("ZKMI_NO_GLV") != nullptr;
+    L.glv = has_glv && !pre && !(flags & ZK_MSM_NO_GLV) && !no_glv && n_points <= GLV_MAX_POINTS;
+    L.entries = L.glv ? 2 * n_points : n_points;
+    int c = window_bits > 0 ? window_bits : pick_window_bits(L.entries);
+    if (window_bits <= 0 && pre && all_windows) {
+        // fixed-base plans over all windows: one shared bucket set makes wider windows affordable (13 windows of
+        // 20 bits instead of 16 of 16: 19 % fewer additions) as long as a table reference still fits the 32-bit
+        // sort entry.  Window-sharded plans keep 16 windows, which split evenly over 2, 4 or 8 ranks.
+        static const int pre_c = getenv("ZKMI_PRE_C") ? atoi(getenv("ZKMI_PRE_C")) : 0;
+        static const bool no_two_level = getenv("ZKMI_NO_TWO_LEVEL") != nullptr;  // wide windows exist in the two-level sort only
+        // Candidates whose TOP window is at least half full: all windows feed one bucket set, and a short top window
+        // (18 bits: 3 scalar bits left for it) would pile its n entries into a handful of buckets of one coarse bin.
+        const int cands[3] = {pre_c ? pre_c : MSM_WIDE_C_DEFAULT, 17, 0};
+        for (int k = 0; !no_two_level && cands[k] > 16; ++k) {
+            const int cand = cands[k];
+            const uint64_t w = (uint64_t)(scalar_bits + 1 + cand - 1) / cand;
+            const int top_bits = scalar_bits + 1 - (int)(w - 1) * cand;
+            // below 2^20 points the wider bucket set costs more in the (latency-bound) reduction than the windows save
+            if (n_points >= (1ull << 20) && w < 16 && (2 * top_bits >= cand || pre_c) && w * n_points <= (1ull << (31 - (cand - 13)))) { c = cand; break; }
+            if (pre_c) break;
+        }
+    }
+    L.c = c;
+    L.nwin = c > 0 ? (L.glv ? (GLV_BITS + c - 1) / c : (scalar_bits + 1 + c - 1) / c) : 0;
+    return L;
+}
 
 struct MsmPlanBase {
     virtual ~MsmPlanBase() {}
@@ -45,6 +106,7 @@ struct MsmPlanBase {
     }
     hipStream_t own_stream = nullptr;  // used when the caller passes ZK_STREAM_PLAN
     int c = 0, nwin = 0;
+    uint64_t entries_per_window = 0;  // points of the plan, doubled when it runs on (P, phi(P)) pairs
     float timings[5] = {0, 0, 0, 0, 0};
     std::mutex mu;
 };

@@ -137,7 +137,8 @@ class Groth16:
             return None
         from ..parallel import window_ranges
         c, nwin = N.ctypes.c_int(0), N.ctypes.c_int(0)
-        N.check(N.load().zk_msm_window_layout(self.E.curve.curve_id, len(arr), 0, c, nwin))
+        flags = N.MSM_PRECOMPUTE if self.precompute_keys else 0
+        N.check(N.load().zk_msm_window_layout(self.E.curve.curve_id, arr.group, len(arr), flags, 0, c, nwin))
         return window_ranges(nwin.value, self._shard[1])[self._shard[0]]
 
     def _build_plan(self, arr, group, slot, high_priority):
