@@ -322,3 +322,38 @@ def test_rccl_code_path_world_size_one(gpu):
     rank, proof_hex, verified, _ = q.get(timeout=300)
     p.join(60)
     assert p.exitcode == 0 and rank == 0 and proof_hex == exp and verified
+
+
+def test_key_file_round_trip_and_pinned_witness(gpu):
+    """a proving key read back from its bytes (batched point decompression, vectors as PointArrays) proves the same bytes
+    as the key it came from, from int lists (repacked into the QAP's page-locked staging rows), from pageable limb arrays
+    and from a page-locked limb array (zk_host_alloc)"""
+    from zksnake_amd.device import PinnedArray
+    cv = pyref.BN254
+    n = 1 << 12
+    A, B, C, w, n_col = W.chain_circuit(n, cv.r)
+    r1cs = R1CS.from_triplets(A, B, C, n, n_col, 2, "BN254")
+    g = Groth16(r1cs, "BN254")
+    g._toxic, g._blinding = TOXIC, BLIND
+    g.setup()
+    proof = g.prove(w[:2], w[2:])
+    kb, vb = g.proving_key.to_bytes(), g.verifying_key.to_bytes()
+    pk = ProvingKey.from_bytes(kb, "BN254")
+    assert pk.to_bytes() == kb and len(pk.tau_1) == len(g.proving_key.tau_1)
+    g2 = Groth16(r1cs, "BN254")
+    g2._blinding = BLIND
+    g2.proving_key, g2.verifying_key = pk, VerifyingKey.from_bytes(vb, "BN254")
+    assert g2.prove(w[:2], w[2:]).to_bytes() == proof.to_bytes()
+    pub, prv = N.ints_to_limbs(w[:2]), N.ints_to_limbs(w[2:])
+    assert g2.prove(pub, prv).to_bytes() == proof.to_bytes()
+    pin = PinnedArray(prv.shape)
+    pin.array[:] = prv
+    assert g2.prove(pub, pin.array).to_bytes() == proof.to_bytes()
+    assert g2.prove(w[:2], pin.array).to_bytes() == proof.to_bytes() and g2.verify(proof, w[:2])
+    pin.free()
+    # a damaged point in the key file is reported like from_hex reports it
+    bad = bytearray(kb)
+    off = 7 * 32 + 8 + 5 * 32    # sixth point of tau_1
+    bad[off:off + 32] = b"\xff" * 32
+    with pytest.raises(N.ZkError, match="Cannot deserialize point"):
+        ProvingKey.from_bytes(bytes(bad), "BN254")
