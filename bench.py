@@ -37,9 +37,10 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_PAIR = 96     # 32 B scalar + 64 B affine base (BN254 G1)
 
 
-# v_mad_u64_u32 per XYZZ mixed addition over a 9-limb field: 6 products (81 + 81 + 9), 2 squarings (45 + 81 + 9) and the
-# Y3 double product with one reduction (162 + 81 + 9)
-MADS_PER_MIXED_ADD = 6 * 171 + 2 * 135 + 252
+# v_mad_u64_u32 per XYZZ mixed addition over a 9-limb field, as the compiled kernel has them (1467 in the ISA of the hot
+# path): 6 products (81 + 81), 2 squarings (45 + 81) and the Y3 double product with one reduction (162 + 81); the 9
+# reduction quotients of every product are v_mul_lo_u32 and are not counted
+MADS_PER_MIXED_ADD = 6 * 162 + 2 * 126 + 243
 
 
 def main():
@@ -207,7 +208,7 @@ def main():
                 "note": "254-bit modular arithmetic makes this kernel integer-VALU bound, not HBM bound; see DESIGN.md",
             },
             # the resource that actually binds: 32-bit integer multiply-add issue.  Per mixed addition the kernel
-            # executes 8 products (2 N^2 + N = 171 v_mad_u64_u32 at N = 9 limbs) and 2 squarings (135); the
+            # executes 8 products (2 N^2 = 162 v_mad_u64_u32 at N = 9 limbs, plus N v_mul_lo_u32) and 2 squarings (126); the
             # peak is the measured chip-wide v_mad_u64_u32 rate (profiles/r01_ubench_valu.log: 26.4 T/s).
             "roofline_valu": {
                 "kernel": "accumulate_kernel<Bn254G1>",
@@ -343,9 +344,9 @@ def extra_metrics(lib, torch, dev, args, bases, d_scalars, expected):
                                              "achieved": round(64 * m / ms / 1e6, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                              "frac": round(64 * m / ms / 1e6 / HBM_PEAK_GBPS, 5),
                                              "note": "64 B/element algorithmic (SURVEY 8d); the passes are bound by integer multiply-add issue"},
-                                "roofline_valu": {"achieved": round(11 * m * 171 / ms / 1e9, 3), "peak": 26.4, "unit": "Tmad/s",
-                                                  "frac": round(11 * m * 171 / ms / 1e9 / 26.4, 4),
-                                                  "note": "log2(n)/2 = 11 field products of 171 v_mad_u64_u32 per element"}}
+                                "roofline_valu": {"achieved": round(11 * m * 162 / ms / 1e9, 3), "peak": 26.4, "unit": "Tmad/s",
+                                                  "frac": round(11 * m * 162 / ms / 1e9 / 26.4, 4),
+                                                  "note": "log2(n)/2 = 11 field products of 162 v_mad_u64_u32 per element"}}
     del d
 
     # (3) Groth16 prove on the benchmark chain circuit (BASELINE config 4), witness as host limb arrays
@@ -505,11 +506,11 @@ PROVE_BYTES_PER_CONSTRAINT = 4 * 96 + 160 + 9 * 64 + 2 * 96 + 3 * 32   # SURVEY 
 
 
 def mads_per_mixed_add(cid, grp):
-    """v_mad_u64_u32 per XYZZ mixed addition: N 29-bit limbs (9 / 14): product 2N^2+N, squaring N(N+1)/2+N^2+N, double
-    product 3N^2+N; G1: six products, two squarings, Y3 as one double product; G2 (Fp2): a product is two double products, a
-    squaring two products"""
+    """v_mad_u64_u32 per XYZZ mixed addition: N 29-bit limbs (9 / 14): product 2N^2, squaring N(N+1)/2+N^2, double
+    product 3N^2 (the N reduction quotients of each are v_mul_lo_u32, not counted); G1: six products, two squarings, Y3 as
+    one double product; G2 (Fp2): a product is two double products, a squaring two products"""
     nl = 9 if cid == 0 else 14
-    mul, sqr, mul2 = 2 * nl * nl + nl, nl * (nl + 1) // 2 + nl * nl + nl, 3 * nl * nl + nl
+    mul, sqr, mul2 = 2 * nl * nl, nl * (nl + 1) // 2 + nl * nl, 3 * nl * nl
     return 6 * mul + 2 * sqr + mul2 if grp == 1 else 8 * (2 * mul2) + 2 * (2 * mul)
 
 

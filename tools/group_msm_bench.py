@@ -14,9 +14,10 @@ import numpy as np  # noqa: E402
 from zksnake_amd import _native as N, workloads as W  # noqa: E402
 from zksnake_amd.device import DeviceBuffer  # noqa: E402
 
-# v_mad_u64_u32 per field operation for N 29-bit limbs: product 2N^2+N, squaring N(N+1)/2+N^2+N, double product 3N^2+N
+# v_mad_u64_u32 per field operation for N 29-bit limbs: product 2N^2, squaring N(N+1)/2+N^2, double product 3N^2
+# (the N reduction quotients of each are v_mul_lo_u32 and are not counted)
 def _mads(nl):
-    return 2 * nl * nl + nl, nl * (nl + 1) // 2 + nl * nl + nl, 3 * nl * nl + nl
+    return 2 * nl * nl, nl * (nl + 1) // 2 + nl * nl, 3 * nl * nl
 
 def mads_per_mixed_add(cid, grp):
     mul, sqr, mul2 = _mads(9 if cid == 0 else 14)
