@@ -252,6 +252,19 @@ def test_msm_2_20_closed_form(gpu):
     _known_dl_case(gpu, n, sc_limbs, sc_ints)
 
 
+@pytest.mark.parametrize("cid,extra", [(0, 0), (0, 3), (1, 0)])
+def test_msm_general_g1_at_the_split_scalar_limit(gpu, cid, extra):
+    """2^22 points is the largest general G1 plan that splits its scalars with the endomorphism (2^23 entries per window,
+    coarse bins above the LDS stage of the second sort level); three points more and the plan keeps the plain windows"""
+    n = (1 << 22) + extra
+    r = (pyref.BN254 if cid == 0 else pyref.BLS12_381).r
+    sc_limbs, sc_ints = W.field_stream(W.SEED_MSM_SCALARS, n, r)
+    lc, ln = N._i(0), N._i(0)
+    N.check(gpu.zk_msm_window_layout(cid, 1, n, 0, 0, lc, ln))
+    assert (lc.value, ln.value) == ((16, 8) if extra == 0 else (16, 16))
+    _known_dl_case(gpu, n, sc_limbs, sc_ints, cid, 1)
+
+
 @pytest.mark.parametrize("cid,grp,log_n", [(0, 2, 16), (1, 1, 18), (1, 2, 15)])
 def test_msm_closed_form_other_groups(gpu, cid, grp, log_n):
     """BN254 G2 and the BLS12-381 twins at sizes where the closed form is the only cheap oracle"""
