@@ -1087,10 +1087,15 @@ __global__ __launch_bounds__(256) void strided_sum_kernel(const uint32_t* __rest
     const bool live = o < job.n_out;  // dead groups still take part in the shuffles
     size_t base = live ? (size_t)(o / job.per_group) * job.group_stride + (size_t)(o % job.per_group) * job.outer : 0;
     HalfPt<F> acc = half_inf<F>();
-    if (live) {
+    if (live && pair < job.count) {
+        // the next point is requested before the current addition starts: a step of the chain is an addition, not a
+        // load followed by an addition
+        HalfPt<F> cur = half_load<F>(in + (base + (size_t)pair * job.inner) * XW, odd);
         for (uint32_t j = pair; j < job.count; j += n_pairs) {
-            HalfPt<F> h = half_load<F>(in + (base + (size_t)j * job.inner) * XW, odd);
-            acc = pair_add<F>(acc, h, odd);
+            const uint32_t jn = j + n_pairs < job.count ? j + n_pairs : j;
+            HalfPt<F> nxt = half_load<F>(in + (base + (size_t)jn * job.inner) * XW, odd);
+            acc = pair_add<F>(acc, cur, odd);
+            cur = nxt;
         }
     }
     for (uint32_t m = lpo >> 1; m >= 2; m >>= 1) {
