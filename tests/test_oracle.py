@@ -33,6 +33,10 @@ def test_public_known_answer_vectors():
         "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8")
     assert R.compress(R.BN254, 1, R.BN254.g1).hex() == "01" + "00" * 31
     assert R.compress(R.BLS12_381, 1, None).hex() == "c0" + "00" * 47
+    # 2 * (1, 2) on alt_bn128: the doubling vector of the EIP-196 precompile tests
+    assert R.Group(R.BN254, 1).mul(R.BN254.g1, 2) == (
+        0x030644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD3,
+        0x15ED738C0E0A7C92E7845F96B2AE9C0A68A6A449E3538FC7FF3EBF7A5A18A2C4)
 
 
 @pytest.mark.parametrize("name,cid", CURVES)
