@@ -33,6 +33,12 @@ def test_public_known_answer_vectors():
         "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8")
     assert R.compress(R.BN254, 1, R.BN254.g1).hex() == "01" + "00" * 31
     assert R.compress(R.BLS12_381, 1, None).hex() == "c0" + "00" * 47
+    # public keys of the BLS secret keys 2 and 3 (compressed 2 G1, 3 G1): they exercise the y-sign flag on both sides
+    g1 = R.Group(R.BLS12_381, 1)
+    assert R.compress(R.BLS12_381, 1, g1.mul(R.BLS12_381.g1, 2)).hex() == (
+        "a572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e")
+    assert R.compress(R.BLS12_381, 1, g1.mul(R.BLS12_381.g1, 3)).hex() == (
+        "89ece308f9d1f0131765212deca99697b112d61f9be9a5f1f3780a51335b3ff981747a0b2ca2179b96d2c0c9024e5224")
     # 2 * (1, 2) on alt_bn128: the doubling vector of the EIP-196 precompile tests
     assert R.Group(R.BN254, 1).mul(R.BN254.g1, 2) == (
         0x030644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD3,
