@@ -99,15 +99,15 @@ class Plonk:
         """<tau_g1[:count], vec[offset:offset+count]> with the scalars read in place from HBM"""
         return self._run_plan(count, vec.ptr(offset), 1)
 
-    def setup(self, g1_tau=None, g2_tau=None):
-        """universal setup (or reuse of given powers of tau) + circuit preprocessing (protocol.py:39-155)"""
+    def setup(self, g1_tau=None, g2_tau=None, prepare_prover=True):
+        """universal setup (or reuse of given powers of tau) + circuit preprocessing (protocol.py:39-155).
+        prepare_prover: also build what every proof reuses (the key's coset evaluations in HBM, the workspaces of the
+        commitments that run side by side), so that the first proof costs what every later one does."""
         V, r = self._ops, self.order
         n = self.constraints.length
         if not g1_tau:
             tau = self._tau if self._tau is not None else get_random_int(r - 1)
-            powers = [1] * (n + 6)
-            for i in range(1, n + 6):
-                powers[i] = powers[i - 1] * tau % r
+            powers = V.d_powers(tau, n + 6).download(n + 6)   # (1, tau, tau^2, ..) as limbs, computed on the device
             self.G1_tau = self.E.batch_mul(self.E.G1(), powers, as_array=True)
             self.G2_tau = self.E.G2() * tau
         else:
@@ -133,6 +133,10 @@ class Plonk:
         pk.tau_permutation_poly = [self._commit(p) for p in perm_poly]
         pk._cache["sigma_evals"] = sigma
         self.verifying_key = VerifyingKey(n, self.G2_tau, pk.tau_selector_poly, pk.tau_permutation_poly, self.E.name)
+        if prepare_prover:
+            self._key_columns()
+            for slot in range(1, 3):   # a round commits to at most three polynomials at once
+                self._tau_plan(slot)
 
     # ------------------------------------------------------------------------------------------
     def _quotient_domain(self):
