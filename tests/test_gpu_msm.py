@@ -438,6 +438,33 @@ def test_fixed_base_plan_ragged_size_above_2_20(gpu):
         N.check(gpu.zk_msm_plan_destroy(h2))
 
 
+@pytest.mark.parametrize("cid,grp,n", [(0, 1, (1 << 21) + 5), (1, 1, 1 << 21), (0, 2, (1 << 20) + (1 << 19))])
+def test_fixed_base_plan_above_2_20_keeps_20_bit_windows(gpu, cid, grp, n):
+    """13 x n table rows no longer fit beside the fine bucket bits in a 32-bit sort entry: the fine bits travel in a byte
+    array of their own and the plan keeps its 13 windows of 20 bits (round 2 fell back to 17-bit windows here)"""
+    r = (pyref.BN254 if cid == 0 else pyref.BLS12_381).r
+    sc_limbs, sc_ints = W.field_stream(0xF00D + n, n, r)
+    k_limbs, k_ints = W.field_stream(0xBEEF + n, n, r)
+    PW = N.point_limbs(cid, grp)
+    gen = generator_limbs(gpu, cid, grp)
+    bases = np.zeros((n, PW), dtype=np.uint64)
+    N.check(gpu.zk_batch_mul(cid, grp, n, N.u64p(k_limbs), N.u64p(gen), 1, N.u64p(bases)))
+    h = N._u64(0)
+    N.check(gpu.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, N.MSM_PRECOMPUTE, 0, h))
+    try:
+        cb, nw = N._i(0), N._i(0)
+        N.check(gpu.zk_msm_plan_windows(h, cb, nw))
+        assert (cb.value, nw.value) == (20, 13)
+        for m in (n, n - 12345):
+            out, exp = np.zeros(PW, dtype=np.uint64), np.zeros(PW, dtype=np.uint64)
+            N.check(gpu.zk_msm_plan_run(h, m, sc_limbs.ctypes.data, 0, 0, 0, N.u64p(out), None))
+            dot = sum(a * b for a, b in zip(sc_ints[:m], k_ints[:m])) % r
+            N.check(gpu.zk_point_mul(cid, grp, N.u64p(gen), N.u64p(N.ints_to_limbs([dot])), N.u64p(exp)))
+            assert (out == exp).all()
+    finally:
+        N.check(gpu.zk_msm_plan_destroy(h))
+
+
 @pytest.mark.parametrize("flags,n", [(1, 5000), (N.MSM_NO_GLV, 5000), (1, 1 << 20)])
 def test_shared_sort_between_g1_and_g2_plans(gpu, flags, n):
     """zk_msm_plan_enqueue_shared: the G2 plan runs on the digits and the sorted entry list of the G1 plan's run in flight

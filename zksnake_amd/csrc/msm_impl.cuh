@@ -683,9 +683,12 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_staged_kernel(
                                                                                 int w_first, int nchunk, uint32_t chunk_len, int fine_log,
                                                                                 int shared_buckets, uint32_t table_stride, int table_w0,
                                                                                 const uint32_t* __restrict__ offsets,
-                                                                                uint32_t* __restrict__ tmp) {
+                                                                                uint32_t* __restrict__ tmp, uint8_t* __restrict__ tmp_fine) {
+    // tmp_fine != nullptr: the reference alone fills the 31 bits below the sign (fixed-base keys above 2^20 points with
+    // 20-bit windows: 13 x 2^22 table rows), and the fine bucket bits travel in a byte array beside the entries
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t wave_tot[SORT_THREADS / 64];
+    const bool split = tmp_fine != nullptr;
     const uint32_t B = 1u << (c - 1), NB = B >> fine_log;
     const uint32_t NBP = (NB + 127) & ~127u;          // multiple of 2 bins x 64 lanes
     const uint32_t per_wave = NBP / (SORT_THREADS / 64);  // bins scanned by one wave: <= 256 (NBP <= 4096)
@@ -694,6 +697,7 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_staged_kernel(
     uint32_t* toff = tcnt + NBP;
     uint32_t* gcur = toff + NBP;
     uint16_t* slot_bin = reinterpret_cast<uint16_t*>(gcur + NBP);
+    uint8_t* slot_fine = reinterpret_cast<uint8_t*>(slot_bin + SCATTER_TILE);   // used when split
     const int index_bits = 31 - fine_log;
     const int wl = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
     const uint32_t* off = offsets + (size_t)blockIdx.x * NB;
@@ -711,6 +715,7 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_staged_kernel(
         const uint32_t i = base + threadIdx.x * 8;
         uint32_t val[8], rank[8];
         uint16_t bin[8];
+        uint8_t fine[8];
         uint32_t dg[8] = {B, B, B, B, B, B, B, B};
         if (i < hi) load8_digits<DIG>(d + i, dg);
 #pragma unroll
@@ -720,7 +725,8 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_staged_kernel(
             if (i + k < hi && v != 0) {
                 const uint32_t b = (uint32_t)(v < 0 ? -v : v) - 1;
                 bin[k] = (uint16_t)(b >> fine_log);
-                val[k] = (v < 0 ? 0x80000000u : 0u) | ((b & ((1u << fine_log) - 1)) << index_bits) | (ref_base + i + k);
+                fine[k] = (uint8_t)(b & ((1u << fine_log) - 1));
+                val[k] = (v < 0 ? 0x80000000u : 0u) | (split ? 0u : ((uint32_t)fine[k] << index_bits)) | (ref_base + i + k);
                 rank[k] = lds_count(tcnt, bin[k]);
             }
         }
@@ -762,13 +768,16 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_staged_kernel(
                 const uint32_t slot = toff[bin[k]] + rank[k];
                 buf[slot] = val[k];
                 slot_bin[slot] = bin[k];
+                if (split) slot_fine[slot] = fine[k];
             }
         }
         __syncthreads();
         const uint32_t count = toff[NBP - 1] + tcnt[NBP - 1];  // entries of this tile
         for (uint32_t sidx = threadIdx.x; sidx < count; sidx += SORT_THREADS) {
             const uint32_t b = slot_bin[sidx];
-            tmp[gcur[b] + (sidx - toff[b])] = buf[sidx];
+            const uint32_t pos = gcur[b] + (sidx - toff[b]);
+            tmp[pos] = buf[sidx];
+            if (split) tmp_fine[pos] = slot_fine[sidx];
         }
         __syncthreads();
         for (uint32_t b = threadIdx.x; b < NBP; b += SORT_THREADS) {
@@ -781,8 +790,10 @@ static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_staged_kernel(
 
 constexpr int SORT_LO_THREADS = 1024;
 
-static __global__ __launch_bounds__(SORT_LO_THREADS) void sort_lo_kernel(const uint32_t* __restrict__ bin_start, const uint32_t* __restrict__ tmp, uint32_t B, int fine_log, uint32_t stage_cap,
+static __global__ __launch_bounds__(SORT_LO_THREADS) void sort_lo_kernel(const uint32_t* __restrict__ bin_start, const uint32_t* __restrict__ tmp, const uint8_t* __restrict__ tmp_fine,
+                                                                         uint32_t B, int fine_log, uint32_t stage_cap,
                                                                          uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ sorted) {
+    const bool split = tmp_fine != nullptr;  // fine bucket bits beside the entries (see scatter_hi_staged_kernel)
     constexpr uint32_t FINE = 1u << FINE_LOG_MAX;  // counters; the upper ones stay zero when fine_log < FINE_LOG_MAX
     __shared__ uint32_t cnt[FINE];
     extern __shared__ uint32_t stage[];  // stage_cap entries
@@ -793,7 +804,7 @@ static __global__ __launch_bounds__(SORT_LO_THREADS) void sort_lo_kernel(const u
     const uint32_t s0 = bin_start[blockIdx.x], s1 = bin_start[blockIdx.x + 1];
     for (uint32_t f = threadIdx.x; f < FINE; f += SORT_LO_THREADS) cnt[f] = 0;
     __syncthreads();
-    for (uint32_t e = s0 + threadIdx.x; e < s1; e += SORT_LO_THREADS) (void)lds_count(cnt, (tmp[e] >> index_bits) & fine_mask);
+    for (uint32_t e = s0 + threadIdx.x; e < s1; e += SORT_LO_THREADS) (void)lds_count(cnt, split ? (uint32_t)tmp_fine[e] : (tmp[e] >> index_bits) & fine_mask);
     __syncthreads();
     if (threadIdx.x < 64) {  // exclusive scan of the 256 counts by one wave: 4 per lane + a shuffle scan
         uint32_t v[4], sum = 0;
@@ -825,8 +836,8 @@ static __global__ __launch_bounds__(SORT_LO_THREADS) void sort_lo_kernel(const u
     const bool staged = s1 - s0 <= stage_cap;
     for (uint32_t e = s0 + threadIdx.x; e < s1; e += SORT_LO_THREADS) {
         const uint32_t t = tmp[e];
-        const uint32_t pos = lds_count(cnt, (t >> index_bits) & fine_mask);
-        const uint32_t ref = (t & 0x80000000u) | (t & ((1u << index_bits) - 1));
+        const uint32_t pos = lds_count(cnt, split ? (uint32_t)tmp_fine[e] : (t >> index_bits) & fine_mask);
+        const uint32_t ref = split ? t : (t & 0x80000000u) | (t & ((1u << index_bits) - 1));
         if (staged) stage[pos] = ref;
         else sorted[s0 + pos] = ref;
     }
@@ -1305,6 +1316,7 @@ struct MsmPlan : MsmPlanBase {
         uint32_t *bsums = nullptr, *grand = nullptr, *big_list = nullptr, *big_count = nullptr;
         uint32_t *sorted = nullptr, *partials = nullptr, *buckets = nullptr, *rows = nullptr, *fin = nullptr;
         uint32_t *tmp_ref = nullptr, *bin_start = nullptr, *slice_sums = nullptr, *bin_tot = nullptr;  // two-level sort
+        uint8_t* tmp_fine = nullptr;  // fine bucket bits of the level-A entries when the reference needs all 31 bits
         hipEvent_t ev_begin = nullptr, ev_acc0 = nullptr, ev_acc1 = nullptr, ev_done = nullptr;
         hipEvent_t ev_release = nullptr;  // recorded by a borrower of this run's sort (enqueue_shared) after its last read
         bool lent = false;
@@ -1335,7 +1347,7 @@ struct MsmPlan : MsmPlanBase {
         // this plan is still in flight
         (void)hipDeviceSynchronize();
         void* bufs[] = {ws.hist, ws.total, ws.bstart, ws.sstart, ws.bsums, ws.grand, ws.big_list, ws.big_count,
-                        ws.sorted, ws.partials, ws.buckets, ws.rows, ws.fin, ws.tmp_ref, ws.bin_start, ws.slice_sums, ws.bin_tot,
+                        ws.sorted, ws.partials, ws.buckets, ws.rows, ws.fin, ws.tmp_ref, ws.tmp_fine, ws.bin_start, ws.slice_sums, ws.bin_tot,
                         d_scalars, d_dig};
         for (void* q : bufs) dev_free_cached(q);
         pinned_free_cached(h_final);
@@ -1448,6 +1460,7 @@ struct MsmPlan : MsmPlanBase {
             ZK_ALLOC(&ws.sorted, entries * 4);
             if (two_level_ok()) {
                 ZK_ALLOC(&ws.tmp_ref, entries * 4);
+                if (split_fine()) ZK_ALLOC(&ws.tmp_fine, entries);
                 ZK_ALLOC(&ws.bin_start, (max_sets * (B >> fine_log_for(n)) + 1) * 4);
                 ZK_ALLOC(&ws.slice_sums, 4096 * BINS_SLICES * 4);
                 ZK_ALLOC(&ws.bin_tot, 4096 * 4);
@@ -1466,7 +1479,7 @@ struct MsmPlan : MsmPlanBase {
         ZK_HIP(hipFuncSetAttribute((const void*)hist_range_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         ZK_HIP(hipFuncSetAttribute((const void*)scatter_range_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         ZK_HIP(hipFuncSetAttribute((const void*)scatter_hi_staged_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        ZK_HIP(hipFuncSetAttribute((const void*)scatter_hi_staged_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        ZK_HIP(hipFuncSetAttribute((const void*)scatter_hi_staged_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
         ZK_HIP(hipFuncSetAttribute((const void*)sort_lo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
         ZK_HIP(hipFuncSetAttribute((const void*)weighted_sum_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(HalfRegs<F>::COUNT * HS_THREADS * 4)));
@@ -1504,8 +1517,8 @@ struct MsmPlan : MsmPlanBase {
         const uint64_t refs = pre ? (uint64_t)pw_count * points : points;
         const uint64_t sets = pre ? 1 : (uint64_t)pw_count;
         if (wide) {
-            const int f = c - 13;  // 4096 coarse bins
-            return refs <= (1ull << (31 - f)) ? f : 0;
+            const int f = c - 13;  // 4096 coarse bins; the fine bits move out of the entry when the reference needs the room
+            return refs <= 0x7FFFFFFFull ? f : 0;
         }
         static const int f_env = getenv("ZKMI_FINE_LOG") ? atoi(getenv("ZKMI_FINE_LOG")) : 0;  // tuning knob (general mode)
         if (f_env && !pre && refs <= (1ull << (31 - f_env)) && c - 1 >= f_env + 2 && sets * (B >> f_env) <= 4096) return f_env;
@@ -1519,6 +1532,12 @@ struct MsmPlan : MsmPlanBase {
             best = f;
         }
         return best;
+    }
+
+    // level-A entries carry (sign, fine bucket bits, reference) in 32 bits while that fits; wide windows over a big table
+    // (13 x n rows, n > 2^20) keep the fine bits in a byte array beside them
+    bool split_fine() const {
+        return wide && pre && (uint64_t)pw_count * n > (1ull << (31 - (c - 13)));
     }
 
     bool two_level_ok() const {
@@ -1588,14 +1607,14 @@ struct MsmPlan : MsmPlanBase {
             }
             {
                 const uint32_t NBP = (NB + 127) & ~127u;
-                const size_t lds_a = (size_t)SCATTER_TILE * 4 + (size_t)NBP * 12 + (size_t)SCATTER_TILE * 2;
-                if (wide) hipLaunchKernelGGL(scatter_hi_staged_kernel<uint32_t>, dim3(w_count * nchunk), dim3(SORT_THREADS), lds_a, st, d_dig32, m, dstride, c, w_first, nchunk, ch8, fl, pre ? 1 : 0, (uint32_t)n, pw_first, l.hist, l.tmp_ref);
-                else hipLaunchKernelGGL(scatter_hi_staged_kernel<uint16_t>, dim3(w_count * nchunk), dim3(SORT_THREADS), lds_a, st, d_dig, m, dstride, c, w_first, nchunk, ch8, fl, pre ? 1 : 0, (uint32_t)n, pw_first, l.hist, l.tmp_ref);
+                const size_t lds_a = (size_t)SCATTER_TILE * 4 + (size_t)NBP * 12 + (size_t)SCATTER_TILE * 2 + (l.tmp_fine ? SCATTER_TILE : 0);
+                if (wide) hipLaunchKernelGGL(scatter_hi_staged_kernel<uint32_t>, dim3(w_count * nchunk), dim3(SORT_THREADS), lds_a, st, d_dig32, m, dstride, c, w_first, nchunk, ch8, fl, pre ? 1 : 0, (uint32_t)n, pw_first, l.hist, l.tmp_ref, l.tmp_fine);
+                else hipLaunchKernelGGL(scatter_hi_staged_kernel<uint16_t>, dim3(w_count * nchunk), dim3(SORT_THREADS), lds_a, st, d_dig, m, dstride, c, w_first, nchunk, ch8, fl, pre ? 1 : 0, (uint32_t)n, pw_first, l.hist, l.tmp_ref, (uint8_t*)nullptr);
             }
             // LDS stage of level B: 1.5x the expected entries of a coarse bin, capped at 96 KiB
             uint64_t expect = ((uint64_t)w_count * m) / ((uint64_t)sets * NB);
             uint32_t stage_cap = (uint32_t)std::min<uint64_t>(24576, std::max<uint64_t>(2048, expect + expect / 2));
-            hipLaunchKernelGGL(sort_lo_kernel, dim3(sets * NB), dim3(SORT_LO_THREADS), (size_t)stage_cap * 4, st, l.bin_start, l.tmp_ref, B, fl, stage_cap, l.bstart, l.sorted);
+            hipLaunchKernelGGL(sort_lo_kernel, dim3(sets * NB), dim3(SORT_LO_THREADS), (size_t)stage_cap * 4, st, l.bin_start, l.tmp_ref, (const uint8_t*)l.tmp_fine, B, fl, stage_cap, l.bstart, l.sorted);
         } else if (ranged) {
             hipLaunchKernelGGL(hist_range_kernel, dim3(w_count * (B >> range_log)), dim3(SORT_THREADS), (4u << range_log), st, d_dig, m, dstride, c, w_first, range_log, l.total);
         } else {

@@ -66,8 +66,8 @@ inline MsmLayout msm_layout(int scalar_bits, bool has_glv, uint64_t n_points, in
     int c = window_bits > 0 ? window_bits : pick_window_bits(L.entries);
     if (window_bits <= 0 && pre && all_windows) {
         // fixed-base plans over all windows: one shared bucket set makes wider windows affordable (13 windows of
-        // 20 bits instead of 16 of 16: 19 % fewer additions) as long as a table reference still fits the 32-bit
-        // sort entry.  Window-sharded plans keep 16 windows, which split evenly over 2, 4 or 8 ranks.
+        // 20 bits instead of 16 of 16: 19 % fewer additions) as long as a table reference fits the 31 bits below the sign of
+        // a sort entry.  Window-sharded plans keep 16 windows, which split evenly over 2, 4 or 8 ranks.
         static const int pre_c = getenv("ZKMI_PRE_C") ? atoi(getenv("ZKMI_PRE_C")) : 0;
         static const bool no_two_level = getenv("ZKMI_NO_TWO_LEVEL") != nullptr;  // wide windows exist in the two-level sort only
         // Candidates whose TOP window is at least half full: all windows feed one bucket set, and a short top window
@@ -78,7 +78,7 @@ inline MsmLayout msm_layout(int scalar_bits, bool has_glv, uint64_t n_points, in
             const uint64_t w = (uint64_t)(scalar_bits + 1 + cand - 1) / cand;
             const int top_bits = scalar_bits + 1 - (int)(w - 1) * cand;
             // below 2^20 points the wider bucket set costs more in the (latency-bound) reduction than the windows save
-            if (n_points >= (1ull << 20) && w < 16 && (2 * top_bits >= cand || pre_c) && w * n_points <= (1ull << (31 - (cand - 13)))) { c = cand; break; }
+            if (n_points >= (1ull << 20) && w < 16 && (2 * top_bits >= cand || pre_c) && w * n_points <= 0x7FFFFFFFull) { c = cand; break; }
             if (pre_c) break;
         }
     }
