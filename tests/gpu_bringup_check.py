@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Quick GPU bring-up check (not a pytest): libzkmi vs the oracle on small/medium sizes, with timings."""
+"""Quick GPU bring-up check (a script, not collected by pytest): libzkmi vs the oracle on small/medium sizes, with
+timings.  Lives under tests/ because it uses the oracle as its checker.  python tests/gpu_bringup_check.py"""
 import sys, os, time, random
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np
