@@ -125,6 +125,12 @@ _lib = None
 _lock = threading.Lock()
 _initialised = False
 
+# A proof keeps seven HIP streams busy (five MSM plans, the QAP chain, the default stream).  The runtime multiplexes streams
+# onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and work of two streams that share a queue runs one after the other:
+# with the default the witness-only MSM and the QAP chain ended up serialised (kernel trace, round 2).  The variable is read
+# when the HIP runtime starts, so it has to be in place before anything touches the GPU; an explicit setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+
 
 def load():
     """dlopen libzkmi.so and attach prototypes; raises if the library has not been built."""
