@@ -177,6 +177,16 @@ int zk_msm_plan_run(uint64_t handle, uint64_t n_scalars, const void* scalars, in
 #define ZK_STREAM_PLAN ((void*)(intptr_t)-1)
 int zk_msm_plan_enqueue(uint64_t handle, uint64_t n_scalars, const void* scalars, int scalars_on_device,
                         int window_first, int window_count, void* stream);
+/* zk_msm_plan_enqueue in two steps, for a caller that keeps several plans in flight and wants their accumulate kernels one
+ * after the other: _sort puts the digits and the sort on the stream, _rest the accumulate kernel -- not before the
+ * accumulate kernel of `after_handle`'s run has finished (0 = no such condition; that run's _rest / enqueue_shared must
+ * have been issued already) -- then the reduction and the D2H copy.  A resident accumulate grid holds every wave slot of
+ * the chip until it ends, so accumulate kernels that run side by side only delay each other's reductions, and the sorts
+ * of plans enqueued later starve behind them; ordered, the sorts run first and every reduction but the last overlaps the
+ * next plan's accumulate kernel.  zk_msm_plan_finish as usual. */
+int zk_msm_plan_enqueue_sort(uint64_t handle, uint64_t n_scalars, const void* scalars, int scalars_on_device,
+                             int window_first, int window_count, void* stream);
+int zk_msm_plan_enqueue_rest(uint64_t handle, uint64_t after_handle);
 /* The same scalars against a second set of bases (Groth16: <tau_1, v> in G1 and <tau_2, v> in G2): run `handle` on the
  * digits and the sorted entry list of `lender_handle`'s run in flight instead of sorting again.  Both plans must have the
  * same size, window layout, mode and window range (else ZK_ERR_ARG: enqueue normally); finish both as usual.  A general-mode

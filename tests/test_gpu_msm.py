@@ -529,3 +529,39 @@ def test_one_level_sort_path_still_correct(gpu):
         res = subprocess.run([sys.executable, os.path.join(root, "tools", "big_msm_check.py")] + args, env=env,
                              capture_output=True, text=True, timeout=300)
         assert res.returncode == 0 and "match=True" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_two_step_enqueue_orders_the_accumulate_kernels(gpu, flags):
+    """zk_msm_plan_enqueue_sort + zk_msm_plan_enqueue_rest: three plans sort side by side, their accumulate kernels run in
+    a chain (each after the previous plan's), the results equal the one-call runs; misuse is refused"""
+    cid, r = 0, pyref.BN254.r
+    n = 60000
+    plans, expect, scal = [], [], []
+    for k, grp in enumerate((1, 2, 1)):
+        bases, _ = _bases_from_library(gpu, cid, grp, n, 0xAB + k)
+        sc = W.field_stream(0x77 + k, n, r)[0]
+        h = N._u64(0)
+        N.check(gpu.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, flags, 0, h))
+        out = np.zeros(N.point_limbs(cid, grp), dtype=np.uint64)
+        N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, 0, 0, N.u64p(out), None))
+        plans.append(h); expect.append(out); scal.append(sc)
+    try:
+        for _ in range(2):
+            for h, sc in zip(plans, scal):
+                N.check(gpu.zk_msm_plan_enqueue_sort(h, n, sc.ctypes.data, 0, 0, 0, N.STREAM_PLAN))
+            tmp = np.zeros(16, dtype=np.uint64)
+            assert gpu.zk_msm_plan_finish(plans[0], N.u64p(tmp)) == N.ZK_ERR_ARG          # accumulate not enqueued yet
+            assert gpu.zk_msm_plan_enqueue_sort(plans[0], n, scal[0].ctypes.data, 0, 0, 0, N.STREAM_PLAN) == N.ZK_ERR_ARG
+            N.check(gpu.zk_msm_plan_enqueue_rest(plans[1], 0))               # the G2 plan first
+            N.check(gpu.zk_msm_plan_enqueue_rest(plans[0], plans[1]))
+            N.check(gpu.zk_msm_plan_enqueue_rest(plans[2], plans[0]))
+            assert gpu.zk_msm_plan_enqueue_rest(plans[2], 0) == N.ZK_ERR_ARG  # nothing sorted any more
+            for h, e in zip(plans, expect):
+                out = np.zeros(e.shape[0], dtype=np.uint64)
+                N.check(gpu.zk_msm_plan_finish(h, N.u64p(out)))
+                assert (out == e).all()
+        assert gpu.zk_msm_plan_enqueue_rest(plans[0], plans[0]) == N.ZK_ERR_ARG
+    finally:
+        for h in plans:
+            N.check(gpu.zk_msm_plan_destroy(h))

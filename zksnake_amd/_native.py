@@ -78,6 +78,8 @@ SIGNATURES = {
     "zk_msm_plan_destroy": (_i, [_u64]),
     "zk_msm_plan_run": (_i, [_u64, _u64, _vp, _i, _i, _i, _u64p, _vp]),
     "zk_msm_plan_enqueue": (_i, [_u64, _u64, _vp, _i, _i, _i, _vp]),
+    "zk_msm_plan_enqueue_sort": (_i, [_u64, _u64, _vp, _i, _i, _i, _vp]),
+    "zk_msm_plan_enqueue_rest": (_i, [_u64, _u64]),
     "zk_msm_plan_enqueue_shared": (_i, [_u64, _u64, _vp]),
     "zk_msm_plan_finish": (_i, [_u64, _u64p]),
     "zk_msm_plan_windows": (_i, [_u64, ctypes.POINTER(_i), ctypes.POINTER(_i)]),

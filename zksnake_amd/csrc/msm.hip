@@ -100,6 +100,20 @@ int zk_msm_plan_enqueue(uint64_t handle, uint64_t n_scalars, const void* scalars
     return p->enqueue(n_scalars, scalars, scalars_on_device, window_first, window_count, pick_stream(p, stream));
 }
 
+int zk_msm_plan_enqueue_sort(uint64_t handle, uint64_t n_scalars, const void* scalars, int scalars_on_device, int window_first,
+                             int window_count, void* stream) {
+    MsmPlanBase* p = find_plan(handle);
+    if (!p) return fail(ZK_ERR_ARG, "unknown MSM plan handle");
+    return p->enqueue_sort(n_scalars, scalars, scalars_on_device, window_first, window_count, pick_stream(p, stream));
+}
+
+int zk_msm_plan_enqueue_rest(uint64_t handle, uint64_t after_handle) {
+    MsmPlanBase* p = find_plan(handle);
+    MsmPlanBase* after = after_handle ? find_plan(after_handle) : nullptr;
+    if (!p || (after_handle && !after) || p == after) return fail(ZK_ERR_ARG, "unknown MSM plan handle");
+    return p->enqueue_rest(after);
+}
+
 int zk_msm_plan_enqueue_shared(uint64_t handle, uint64_t lender_handle, void* stream) {
     MsmPlanBase* p = find_plan(handle);
     MsmPlanBase* lender = find_plan(lender_handle);

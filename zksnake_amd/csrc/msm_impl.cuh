@@ -1317,7 +1317,7 @@ struct MsmPlan : MsmPlanBase {
         uint32_t *sorted = nullptr, *partials = nullptr, *buckets = nullptr, *rows = nullptr, *fin = nullptr;
         uint32_t *tmp_ref = nullptr, *bin_start = nullptr, *slice_sums = nullptr, *bin_tot = nullptr;  // two-level sort
         uint8_t* tmp_fine = nullptr;  // fine bucket bits of the level-A entries when the reference needs all 31 bits
-        hipEvent_t ev_begin = nullptr, ev_acc0 = nullptr, ev_acc1 = nullptr, ev_done = nullptr;
+        hipEvent_t ev_begin = nullptr, ev_acc0 = nullptr, ev_accs = nullptr, ev_acc1 = nullptr, ev_done = nullptr;
         hipEvent_t ev_release = nullptr;  // recorded by a borrower of this run's sort (enqueue_shared) after its last read
         bool lent = false;
         uint32_t seg_len = 0;
@@ -1351,7 +1351,7 @@ struct MsmPlan : MsmPlanBase {
                         d_scalars, d_dig};
         for (void* q : bufs) dev_free_cached(q);
         pinned_free_cached(h_final);
-        for (hipEvent_t e : {ws.ev_begin, ws.ev_acc0, ws.ev_acc1, ws.ev_done, ws.ev_release, ev_start, ev_digits, ev_end}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ws.ev_begin, ws.ev_acc0, ws.ev_accs, ws.ev_acc1, ws.ev_done, ws.ev_release, ev_start, ev_digits, ev_end}) if (e) (void)hipEventDestroy(e);
         stream_release((create_flags & ZK_MSM_HIGH_PRIORITY) != 0, own_stream);
     }
 
@@ -1469,7 +1469,7 @@ struct MsmPlan : MsmPlanBase {
             ZK_ALLOC(&ws.buckets, keys * XW * 4);
             ZK_ALLOC(&ws.rows, max_sets * (R + C) * XW * 4);
             ZK_ALLOC(&ws.fin, max_sets * (bpr + bpc) * 2 * XW * 4);
-            for (hipEvent_t* e : {&ws.ev_begin, &ws.ev_acc0, &ws.ev_acc1, &ws.ev_done, &ws.ev_release}) ZK_HIP(hipEventCreate(e));
+            for (hipEvent_t* e : {&ws.ev_begin, &ws.ev_acc0, &ws.ev_accs, &ws.ev_acc1, &ws.ev_done, &ws.ev_release}) ZK_HIP(hipEventCreate(e));
         }
         mark("workspace + events");
         // LDS above 64 KiB needs the opt-in
@@ -1565,7 +1565,10 @@ struct MsmPlan : MsmPlanBase {
 
     // stages 2..7 + D2H for the windows [ws.w_first, ws.w_first + ws.w_count) on stream st
     // `borrowed`: the digits and the sort of another plan's run over the same scalars (enqueue_shared); stages 1-4 are skipped
-    int run_stages(uint32_t m, uint32_t dstride, hipStream_t st, const SortExport* borrowed = nullptr) {
+    // phase: 0 = everything, 1 = up to the sorted entry list only, 2 = from the accumulate kernel on (after phase 1).
+    // gate: waited for right before the accumulate kernel (another plan's accumulate has finished), so that the
+    // accumulate kernels of several plans run one after the other while their sorts and reductions overlap.
+    int run_stages(uint32_t m, uint32_t dstride, hipStream_t st, const SortExport* borrowed = nullptr, int phase = 0, hipEvent_t gate = nullptr) {
         Work& l = ws;
         const int w_first = l.w_first, w_count = l.w_count;
         const uint32_t groups = l.groups;
@@ -1574,9 +1577,11 @@ struct MsmPlan : MsmPlanBase {
         const uint32_t seg_len = borrowed ? borrowed->seg_len : pick_seg_len((uint64_t)w_count * m);
         l.seg_len = seg_len;
         const uint32_t ch_len = (m + nchunk - 1) / nchunk;
-        ZK_HIP(hipEventRecord(l.ev_begin, st));
+        if (phase != 2) ZK_HIP(hipEventRecord(l.ev_begin, st));
         const uint32_t *p_sorted = l.sorted, *p_bstart = l.bstart, *p_sstart = l.sstart, *p_big_list = l.big_list, *p_big_count = l.big_count;
-        if (borrowed) {
+        if (phase == 2) {
+            // sorted in phase 1
+        } else if (borrowed) {
             p_sorted = borrowed->sorted; p_bstart = borrowed->bstart; p_sstart = borrowed->sstart;
             p_big_list = borrowed->big_list; p_big_count = borrowed->big_count;
             ZK_HIP(hipStreamWaitEvent(st, borrowed->sorted_ready, 0));
@@ -1639,7 +1644,10 @@ struct MsmPlan : MsmPlanBase {
             hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(SORT_THREADS), B * 4, st, d_dig, m, dstride, c, w_first, w_count, nchunk, ch_len, pre ? 1 : 0, (uint32_t)n, pw_first, l.hist, l.bstart, l.sorted);
         }
         }  // !borrowed
-        ZK_HIP(hipEventRecord(l.ev_acc0, st));
+        if (phase != 2) ZK_HIP(hipEventRecord(l.ev_acc0, st));
+        if (phase == 1) return ZK_OK;
+        if (gate) ZK_HIP(hipStreamWaitEvent(st, gate, 0));
+        ZK_HIP(hipEventRecord(l.ev_accs, st));
         // 5. accumulate
         uint64_t lanes_needed = ((uint64_t)w_count * m + seg_len - 1) / seg_len;
         hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((lanes_needed + 255) / 256)), dim3(256), 0, st, d_bases, p_sorted, p_bstart, p_sstart, n_keys, seg_len, l.partials, l.buckets);
@@ -1684,9 +1692,31 @@ struct MsmPlan : MsmPlanBase {
     hipStream_t q_stream = nullptr;
     bool q_pending = false;
 
+    bool q_sorted = false;  // enqueue_sort done, enqueue_rest still to come
+
     int enqueue(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count, hipStream_t st) override {
+        return enqueue_phase(n_scalars, scalars, on_device, w_first, w_count, st, 0);
+    }
+    int enqueue_sort(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count, hipStream_t st) override {
+        return enqueue_phase(n_scalars, scalars, on_device, w_first, w_count, st, 1);
+    }
+    hipEvent_t accumulate_done_event() override { return ws.ev_acc1; }
+    int enqueue_rest(MsmPlanBase* after) override {
         std::lock_guard<std::mutex> lock(mu);
-        if (q_pending) return fail(ZK_ERR_ARG, "MSM plan already has a run in flight: call zk_msm_plan_finish first");
+        if (!q_sorted) return fail(ZK_ERR_ARG, "zk_msm_plan_enqueue_rest without zk_msm_plan_enqueue_sort");
+        q_sorted = false;
+        if (q_m > 0) {
+            int rc = run_stages(q_m, (q_m + 7u) & ~7u, q_stream, nullptr, 2, after ? after->accumulate_done_event() : nullptr);
+            if (rc) return rc;
+            ZK_HIP(hipEventRecord(ev_end, q_stream));
+        }
+        q_pending = true;
+        return ZK_OK;
+    }
+
+    int enqueue_phase(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count, hipStream_t st, int phase) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (q_pending || q_sorted) return fail(ZK_ERR_ARG, "MSM plan already has a run in flight: call zk_msm_plan_finish first");
         if (n_scalars > n_api) return fail(ZK_ERR_LENGTH, "Number of points and scalars mismatch");
         if (w_count <= 0) { w_first = pw_first; w_count = pw_count; }
         if (w_first < pw_first || w_first + w_count > pw_first + pw_count)
@@ -1727,17 +1757,18 @@ struct MsmPlan : MsmPlanBase {
             ws.w_first = w_first;
             ws.w_count = w_count;
             ws.groups = pre ? 1u : (uint32_t)w_count;
-            int rc = run_stages(m, dstride, st);
+            int rc = run_stages(m, dstride, st, nullptr, phase);
             if (rc) return rc;
-            ZK_HIP(hipEventRecord(ev_end, st));
+            if (phase == 0) ZK_HIP(hipEventRecord(ev_end, st));
         }
-        q_pending = true;
+        if (phase == 1) q_sorted = true;
+        else q_pending = true;
         return ZK_OK;
     }
 
     int export_sort(SortExport* out) override {
         std::lock_guard<std::mutex> lock(mu);
-        if (!q_pending || q_m == 0) return fail(ZK_ERR_ARG, "the lending plan has no run in flight");
+        if ((!q_pending && !q_sorted) || q_m == 0) return fail(ZK_ERR_ARG, "the lending plan has no run in flight");
         out->sorted = ws.sorted; out->bstart = ws.bstart; out->sstart = ws.sstart;
         out->big_list = ws.big_list; out->big_count = ws.big_count;
         out->n = n; out->m = q_m; out->seg_len = ws.seg_len; out->groups = ws.groups;
@@ -1757,7 +1788,7 @@ struct MsmPlan : MsmPlanBase {
         int rc = lender->export_sort(&ex);
         if (rc) return rc;
         std::lock_guard<std::mutex> lock(mu);
-        if (q_pending) return fail(ZK_ERR_ARG, "MSM plan already has a run in flight: call zk_msm_plan_finish first");
+        if (q_pending || q_sorted) return fail(ZK_ERR_ARG, "MSM plan already has a run in flight: call zk_msm_plan_finish first");
         if (ex.n != n || ex.c != c || ex.nwin != nwin || ex.pre != pre || ex.glv != glv || ex.scalar_bits != FrP::BITS ||
             ex.pw_first != pw_first || ex.pw_count != pw_count)
             return fail(ZK_ERR_ARG, "plans differ in size, window layout or mode: the sort cannot be shared");
@@ -1780,6 +1811,7 @@ struct MsmPlan : MsmPlanBase {
 
     int finish(uint64_t* out) override {
         std::lock_guard<std::mutex> lock(mu);
+        if (q_sorted) return fail(ZK_ERR_ARG, "zk_msm_plan_finish before zk_msm_plan_enqueue_rest");
         if (!q_pending) return fail(ZK_ERR_ARG, "zk_msm_plan_finish without a pending run");
         q_pending = false;
         typedef typename G::HostF HF;  // 64-bit-limb host arithmetic for the sequential tail (host64.cuh)
@@ -1838,7 +1870,7 @@ struct MsmPlan : MsmPlanBase {
             if (!pre) for (int k = 0; k < c * q_first; ++k) total = xyzz_dbl<HF>(total);
             float sort_ms = 0, acc_ms = 0, red_ms = 0, t = 0;
             if (hipEventElapsedTime(&t, ws.ev_begin, ws.ev_acc0) == hipSuccess) sort_ms += t;
-            if (hipEventElapsedTime(&t, ws.ev_acc0, ws.ev_acc1) == hipSuccess) acc_ms += t;
+            if (hipEventElapsedTime(&t, ws.ev_accs, ws.ev_acc1) == hipSuccess) acc_ms += t;
             if (hipEventElapsedTime(&t, ws.ev_acc1, ws.ev_done) == hipSuccess) red_ms += t;
             if (hipEventElapsedTime(&t, ev_start, ev_digits) == hipSuccess) sort_ms += t;
             timings[0] = sort_ms;   // digits + sort

@@ -98,6 +98,13 @@ struct MsmPlanBase {
     // finish() waits for them and runs the host tail.  run() = enqueue() + finish().
     virtual int enqueue(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count,
                         hipStream_t stream) = 0;
+    // the same in two steps, for a caller that orders the accumulate kernels of several plans: enqueue_sort puts the
+    // digits and the sort on the stream; enqueue_rest the accumulate kernel (after `after`'s, if given), the reduction and
+    // the D2H copy.  Left to themselves the accumulate kernels of concurrent plans share the machine and the sorts of
+    // later plans starve behind them (a resident accumulate grid holds every wave slot until it ends).
+    virtual int enqueue_sort(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count, hipStream_t stream) = 0;
+    virtual int enqueue_rest(MsmPlanBase* after) = 0;
+    virtual hipEvent_t accumulate_done_event() = 0;
     virtual int finish(uint64_t* out) = 0;
     int run(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count, uint64_t* out,
             hipStream_t stream) {

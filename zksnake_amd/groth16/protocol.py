@@ -179,9 +179,10 @@ class Groth16:
                 if isinstance(arr, PointArray) and arr.window_range is None:
                     arr.release()
 
-    def _enqueue_msm(self, bases, group, d_scalars, count, slot=0, high_priority=False, share_sort_of=None):
+    def _enqueue_msm(self, bases, group, d_scalars, count, slot=0, high_priority=False, share_sort_of=None, sort_only=False):
         """start <bases[:count], scalars> (scalars already in HBM) on the plan's own stream; with sharding only
-        this rank's windows.  Returns (array, handle); handle None = this rank has no window of that MSM."""
+        this rank's windows.  Returns (array, handle); handle None = this rank has no window of that MSM.
+        sort_only: digits and sort only -- the accumulate kernel and the reduction follow with _enqueue_rest."""
         lib = N.load()
         arr = _as_array(self.E, bases, group)
         first, cnt = 0, 0  # 0, 0 = all windows
@@ -198,8 +199,16 @@ class Groth16:
             # <tau_1, v> is already in flight with the same scalars: B2 = <tau_2, v> reuses its digits and sorted entries
             if lib.zk_msm_plan_enqueue_shared(handle, share_sort_of, N.STREAM_PLAN) == N.ZK_OK:
                 return arr, handle
-        N.check(lib.zk_msm_plan_enqueue(handle, count, d_scalars, 1, first, cnt, N.STREAM_PLAN))
+        enqueue = lib.zk_msm_plan_enqueue_sort if sort_only else lib.zk_msm_plan_enqueue
+        N.check(enqueue(handle, count, d_scalars, 1, first, cnt, N.STREAM_PLAN))
         return arr, handle
+
+    @staticmethod
+    def _enqueue_rest(handle, after):
+        """accumulate kernel, reduction and D2H of a plan whose sort is in flight, the accumulate kernel not before that of
+        `after` (a handle or None) has finished"""
+        if handle is not None:
+            N.check(N.load().zk_msm_plan_enqueue_rest(handle, after or 0))
 
     def _finish_msm(self, handle, group):
         """affine limbs of the (partial) MSM result; all-zero = infinity"""
@@ -265,13 +274,24 @@ class Groth16:
 
         t_qap = time.perf_counter()
         n = res.n
-        # the four MSMs over u, v, h are put in flight on their plans' own streams, then collected: the latency-bound
-        # bucket reductions of one overlap with the accumulation kernels of the others.  The G2 MSM (three times the
-        # work of a G1 one, and the longest reduction tail) goes first, on a high-priority stream.
-        pk.tau_1, h_v1 = self._enqueue_msm(pk.tau_1, 1, res.v.ptr, min(n, len(pk.tau_1)), slot=1)
+        # The four MSMs over u, v, h run on their plans' own streams.  An accumulate kernel fills every wave slot of the
+        # chip until it ends: left to themselves two of them only slow each other down and the sorts of the plans behind
+        # them starve.  So the three sorts go first, side by side, and the accumulate kernels run one after the other,
+        # the G2 one (three times the work of a G1 one, and the longest reduction tail) at the head: every reduction but
+        # the last overlaps the next plan's accumulate kernel.
+        ordered = not os.environ.get("ZKMI_UNORDERED_MSMS")
+        pk.tau_1, h_v1 = self._enqueue_msm(pk.tau_1, 1, res.v.ptr, min(n, len(pk.tau_1)), slot=1, sort_only=ordered)
+        if ordered:
+            pk.tau_1, h_u = self._enqueue_msm(pk.tau_1, 1, res.u.ptr, min(n, len(pk.tau_1)), slot=0, sort_only=True)
+            pk.target_1, h_h = self._enqueue_msm(pk.target_1, 1, res.h.ptr, min(n, len(pk.target_1)), sort_only=True)
         pk.tau_2, h_v2 = self._enqueue_msm(pk.tau_2, 2, res.v.ptr, min(n, len(pk.tau_2)), high_priority=True, share_sort_of=h_v1)
-        pk.tau_1, h_u = self._enqueue_msm(pk.tau_1, 1, res.u.ptr, min(n, len(pk.tau_1)), slot=0)
-        pk.target_1, h_h = self._enqueue_msm(pk.target_1, 1, res.h.ptr, min(n, len(pk.target_1)))
+        if ordered:
+            self._enqueue_rest(h_v1, h_v2)
+            self._enqueue_rest(h_u, h_v1 or h_v2)
+            self._enqueue_rest(h_h, h_u or h_v1 or h_v2)
+        else:
+            pk.tau_1, h_u = self._enqueue_msm(pk.tau_1, 1, res.u.ptr, min(n, len(pk.tau_1)), slot=0)
+            pk.target_1, h_h = self._enqueue_msm(pk.target_1, 1, res.h.ptr, min(n, len(pk.target_1)))
         h_k = early.get("k")
         t_enq = time.perf_counter()
         # the blinding terms depend on the key and (r, s) only: the host computes them (four scalar multiplications,
