@@ -300,8 +300,13 @@ class Groth16:
         b1_fixed = pk.beta_1 + pk.delta_1 * s
         b2_fixed = pk.beta_2 + pk.delta_2 * s
         c_fixed = (-pk.delta_1) * (r * s % q)
-        parts = [(self._finish_msm(h_u, 1), 1), (self._finish_msm(h_v2, 2), 2), (self._finish_msm(h_v1, 1), 1),
-                 (self._finish_msm(h_h, 1), 1), (self._finish_msm(h_k, 1), 1)]
+        # collected in the order the GPU completes them, so that only the last host tail is left once the GPU is idle
+        f_k = self._finish_msm(h_k, 1)
+        f_v2 = self._finish_msm(h_v2, 2)
+        f_v1 = self._finish_msm(h_v1, 1)
+        f_u = self._finish_msm(h_u, 1)
+        f_h = self._finish_msm(h_h, 1)
+        parts = [(f_u, 1), (f_v2, 2), (f_v1, 1), (f_h, 1), (f_k, 1)]
         t_fin = time.perf_counter()
         msm_u, msm_v2, msm_v1, HZ, sum_delta_witness = self._exchange(parts)
 
