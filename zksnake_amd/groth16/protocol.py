@@ -305,15 +305,26 @@ class Groth16:
         f_v2 = self._finish_msm(h_v2, 2)
         f_v1 = self._finish_msm(h_v1, 1)
         f_u = self._finish_msm(h_u, 1)
-        f_h = self._finish_msm(h_h, 1)
-        parts = [(f_u, 1), (f_v2, 2), (f_v1, 1), (f_h, 1), (f_k, 1)]
-        t_fin = time.perf_counter()
-        msm_u, msm_v2, msm_v1, HZ, sum_delta_witness = self._exchange(parts)
-
-        A = msm_u + a_fixed
-        B1 = msm_v1 + b1_fixed
-        B2 = msm_v2 + b2_fixed
-        C = HZ + sum_delta_witness + A * s + B1 * r + c_fixed
+        if self._shard is None or self._shard[1] <= 1:
+            # A, B and the two scalar multiplications of C need <tau, u> and <tau, v> only: done on the host while the GPU
+            # still works on <target_1, h>, the last MSM of the chain
+            msm_u, msm_v2, msm_v1, sum_delta_witness = self._exchange([(f_u, 1), (f_v2, 2), (f_v1, 1), (f_k, 1)])
+            A = msm_u + a_fixed
+            B1 = msm_v1 + b1_fixed
+            B2 = msm_v2 + b2_fixed
+            c_partial = sum_delta_witness + A * s + B1 * r + c_fixed
+            f_h = self._finish_msm(h_h, 1)
+            t_fin = time.perf_counter()
+            (HZ,) = self._exchange([(f_h, 1)])
+            C = HZ + c_partial
+        else:
+            f_h = self._finish_msm(h_h, 1)
+            t_fin = time.perf_counter()
+            msm_u, msm_v2, msm_v1, HZ, sum_delta_witness = self._exchange([(f_u, 1), (f_v2, 2), (f_v1, 1), (f_h, 1), (f_k, 1)])
+            A = msm_u + a_fixed
+            B1 = msm_v1 + b1_fixed
+            B2 = msm_v2 + b2_fixed
+            C = HZ + sum_delta_witness + A * s + B1 * r + c_fixed
         t_end = time.perf_counter()
         self.last_timings = {"qap_ms": (t_qap - t_start) * 1e3, "msm_enqueue_ms": (t_enq - t_qap) * 1e3,
                              "msm_finish_ms": (t_fin - t_enq) * 1e3, "exchange_assemble_ms": (t_end - t_fin) * 1e3}
