@@ -1078,6 +1078,8 @@ __global__ __launch_bounds__(COMBINE_THREADS) void combine_kernel(const uint32_t
 struct SumJob {
     uint32_t n_out, per_group, group_stride, outer, inner, count;
     uint32_t out_offset;  // in points, into the shared output array
+    uint32_t split = 1, outer2 = 0;  // the index x inside a group is taken apart: (x / split) * outer + (x % split) * outer2
+    uint32_t in_offset = 0;          // in points, into the input array
 };
 
 template <class G>
@@ -1096,7 +1098,8 @@ __global__ __launch_bounds__(256) void strided_sum_kernel(const uint32_t* __rest
         job = j1;
     }
     const bool live = o < job.n_out;  // dead groups still take part in the shuffles
-    size_t base = live ? (size_t)(o / job.per_group) * job.group_stride + (size_t)(o % job.per_group) * job.outer : 0;
+    const uint32_t x = live ? o % job.per_group : 0;
+    size_t base = live ? (size_t)job.in_offset + (size_t)(o / job.per_group) * job.group_stride + (size_t)(x / job.split) * job.outer + (size_t)(x % job.split) * job.outer2 : 0;
     HalfPt<F> acc = half_inf<F>();
     if (live && pair < job.count) {
         // the next point is requested before the current addition starts: a step of the chain is an addition, not a
@@ -1315,6 +1318,7 @@ struct MsmPlan : MsmPlanBase {
         uint32_t *hist = nullptr, *total = nullptr, *bstart = nullptr, *sstart = nullptr;
         uint32_t *bsums = nullptr, *grand = nullptr, *big_list = nullptr, *big_count = nullptr;
         uint32_t *sorted = nullptr, *partials = nullptr, *buckets = nullptr, *rows = nullptr, *fin = nullptr;
+        uint32_t* parts = nullptr;  // partial row / column sums of the two-step strided sums
         uint32_t *tmp_ref = nullptr, *bin_start = nullptr, *slice_sums = nullptr, *bin_tot = nullptr;  // two-level sort
         uint8_t* tmp_fine = nullptr;  // fine bucket bits of the level-A entries when the reference needs all 31 bits
         hipEvent_t ev_begin = nullptr, ev_acc0 = nullptr, ev_accs = nullptr, ev_acc1 = nullptr, ev_done = nullptr;
@@ -1347,7 +1351,7 @@ struct MsmPlan : MsmPlanBase {
         // this plan is still in flight
         (void)hipDeviceSynchronize();
         void* bufs[] = {ws.hist, ws.total, ws.bstart, ws.sstart, ws.bsums, ws.grand, ws.big_list, ws.big_count,
-                        ws.sorted, ws.partials, ws.buckets, ws.rows, ws.fin, ws.tmp_ref, ws.tmp_fine, ws.bin_start, ws.slice_sums, ws.bin_tot,
+                        ws.sorted, ws.partials, ws.buckets, ws.rows, ws.parts, ws.fin, ws.tmp_ref, ws.tmp_fine, ws.bin_start, ws.slice_sums, ws.bin_tot,
                         d_scalars, d_dig};
         for (void* q : bufs) dev_free_cached(q);
         pinned_free_cached(h_final);
@@ -1468,6 +1472,7 @@ struct MsmPlan : MsmPlanBase {
             ZK_ALLOC(&ws.partials, max_segs * XW * 4);
             ZK_ALLOC(&ws.buckets, keys * XW * 4);
             ZK_ALLOC(&ws.rows, max_sets * (R + C) * XW * 4);
+            if (sum_part_len() >= 2) ZK_ALLOC(&ws.parts, max_sets * 2 * (uint64_t)(B / sum_part_len()) * XW * 4);
             ZK_ALLOC(&ws.fin, max_sets * (bpr + bpc) * 2 * XW * 4);
             for (hipEvent_t* e : {&ws.ev_begin, &ws.ev_acc0, &ws.ev_accs, &ws.ev_acc1, &ws.ev_done, &ws.ev_release}) ZK_HIP(hipEventCreate(e));
         }
@@ -1538,6 +1543,12 @@ struct MsmPlan : MsmPlanBase {
     // (13 x n rows, n > 2^20) keep the fine bits in a byte array beside them
     bool split_fine() const {
         return wide && pre && (uint64_t)pw_count * n > (1ull << (31 - (c - 13)));
+    }
+
+    // buckets one lane pair adds up in the first step of the two-step strided sums (0 = one step)
+    uint32_t sum_part_len() const {
+        const uint32_t k = 16u;
+        return (R >= 4 * k && C >= 4 * k) ? k : 0u;
     }
 
     bool two_level_ok() const {
@@ -1661,11 +1672,30 @@ struct MsmPlan : MsmPlanBase {
         uint32_t n_rows = groups * R, n_cols = groups * C;
         SumJob rows = {n_rows, R, B, C, 1u, C, 0u};
         SumJob cols = {n_cols, C, B, 1u, C, R, n_rows};
+        // Two steps when the sums are long: one lane pair walks a run of K buckets with no idle lanes (the tree of the
+        // one-step form leaves half of its lane-steps empty), then a short tree adds the R / K or C / K partial sums.
+        static const bool one_step = getenv("ZKMI_SUM_ONE_STEP") != nullptr;  // A/B knob
+        // worth it from 2^18 buckets on (8 windows of 2^15, or the 2^19-bucket set of a fixed-base plan): with fewer the sums
+        // are a latency chain and the second launch only lengthens it (measured: 2^17 buckets 0.223 vs 0.212 ms)
+        const uint32_t K = (one_step || n_keys < (1u << 18)) ? 0u : sum_part_len();
+        if (K >= 2 && l.parts && C % K == 0 && R % K == 0 && C / K >= 2 && R / K >= 2) {
+            const uint32_t pr = C / K, pc = R / K;  // partial sums per row sum / per column sum
+            // step 1: partial (row r, part p) = sum of buckets r C + p K + [0, K); (column j, part p) = sum of (p K + i) C + j
+            SumJob prow = {n_rows * pr, R * pr, B, C, 1u, K, 0u, pr, K};
+            SumJob pcol = {n_cols * pc, C * pc, B, 1u, C, K, n_rows * pr, pc, K * C};
+            hipLaunchKernelGGL(strided_sum_kernel<G>, dim3((unsigned)((((uint64_t)prow.n_out + pcol.n_out) * 2 + 255) / 256)), dim3(256), 0, st, l.buckets, l.parts, prow, pcol, 2u);
+            // step 2: contiguous runs of pr (pc) partial sums
+            SumJob frow = {n_rows, n_rows, 0u, pr, 1u, pr, 0u};
+            SumJob fcol = {n_cols, n_cols, 0u, pc, 1u, pc, n_rows, 1u, 0u, n_rows * pr};
+            const uint32_t lpo2 = 2 * std::min<uint32_t>(32u, std::max(pr, pc) / 2);
+            hipLaunchKernelGGL(strided_sum_kernel<G>, dim3(((n_rows + n_cols) * lpo2 + 255) / 256), dim3(256), 0, st, l.parts, l.rows, frow, fcol, lpo2);
+        } else {
         // lanes per output (two lanes = one point): many outputs (one bucket set per window) -> 16 pairs each walk
         // count/16 buckets and finish with a 4-level tree; few outputs (shared bucket set) -> 32 pairs, shortest chain
         static const uint32_t lpo_env = getenv("ZKMI_LPO") ? (uint32_t)atoi(getenv("ZKMI_LPO")) : 0u;
         const uint32_t lpo = lpo_env ? lpo_env : ((n_rows + n_cols) >= 4096 ? 32u : 64u);
         hipLaunchKernelGGL(strided_sum_kernel<G>, dim3(((n_rows + n_cols) * lpo + 255) / 256), dim3(256), 0, st, l.buckets, l.rows, rows, cols, lpo);
+        }
         hipLaunchKernelGGL(weighted_sum_kernel<G>, dim3(groups * (bpr + bpc)), dim3(HS_THREADS), (size_t)HalfRegs<F>::COUNT * HS_THREADS * 4, st,
                            l.rows, R, groups, l.rows + (size_t)n_rows * XW, C, l.fin);
         ZK_HIP(hipGetLastError());
