@@ -239,6 +239,10 @@ int zk_vec_gather_dev(int curve, uint64_t n, const void* d_src, uint64_t stride,
 int zk_vec_is_zero_dev(int curve, uint64_t n, const void* d_x, int* is_zero, void* stream);
 /* out = sum_i coeffs[i] x^i (Polynomial.__call__, src/bn254/polynomial.rs:491-516); synchronises the stream */
 int zk_poly_eval_dev(int curve, uint64_t n, const void* d_coeffs, const uint64_t* x, uint64_t* out, void* stream);
+/* k evaluations, polynomial i at xs[i] (4 limbs each) into outs[i], with a single synchronisation (the five opening values
+ * and PI(zeta) of a PlonK proof, protocol.py:400-420) */
+int zk_poly_eval_many_dev(int curve, int k, const uint64_t* counts, const void* const* d_coeffs, const uint64_t* xs, uint64_t* outs,
+                          void* stream);
 /* out[i] = prod_{j<3} (wires[j][i] + beta*labels[j][i] + gamma): numerator / denominator terms of the grand product
  * (protocol.py:270-292), labels = the identity or the sigma columns on the n-domain */
 int zk_plonk_perm_terms_dev(int curve, uint64_t n, const void* const* d_wires, const void* const* d_labels, const uint64_t* beta,

@@ -101,6 +101,7 @@ SIGNATURES = {
     "zk_vec_gather_dev": (_i, [_i, _u64, _vp, _u64, _u64, _vp, _vp]),
     "zk_vec_is_zero_dev": (_i, [_i, _u64, _vp, ctypes.POINTER(_i), _vp]),
     "zk_poly_eval_dev": (_i, [_i, _u64, _vp, _u64p, _u64p, _vp]),
+    "zk_poly_eval_many_dev": (_i, [_i, _i, _u64p, ctypes.POINTER(_vp), _u64p, _u64p, _vp]),
     "zk_plonk_grand_product_dev": (_i, [_i, _u64, _vp, _vp, _vp, _vp]),
     "zk_poly_div_linear_dev": (_i, [_i, _u64, _vp, _u64p, _vp, _u64p, _vp]),
     "zk_plonk_perm_terms_dev": (_i, [_i, _u64, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _u64p, _u64p, _vp, _vp]),

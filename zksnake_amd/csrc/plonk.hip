@@ -294,7 +294,7 @@ template <class P>
 static int grand_product_dev_impl(uint64_t n, const void* num, const void* den, void* out, hipStream_t st) {
     const size_t eb = P::W * 4;
     uint32_t* work = nullptr;  // PN (n+1) | SD (n+1) | partials
-    ZK_HIP(hipMalloc(&work, (2 * (n + 1) + SCAN_MAX_PARTIALS) * eb));
+    ZK_ALLOC(&work, (2 * (n + 1) + SCAN_MAX_PARTIALS) * eb);
     uint32_t *pn = work, *sd = work + (n + 1) * P::W, *partial = work + 2 * (n + 1) * P::W;
     int rc = ZK_OK;
     do {
@@ -316,7 +316,7 @@ static int grand_product_dev_impl(uint64_t n, const void* num, const void* den, 
         hipLaunchKernelGGL(grand_product_finish_kernel<P>, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, n + 1, pn, sd, dinv, (uint32_t*)out);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = fail(ZK_ERR_HIP, "grand product: finish failed");
     } while (0);
-    (void)hipFree(work);
+    dev_free_cached(work);
     return rc;
 }
 
@@ -335,7 +335,7 @@ static int div_linear_dev_impl(uint64_t n, const void* coeffs, const uint64_t* r
         return ZK_OK;
     }
     uint32_t* work = nullptr;  // b / SS (n) | partials
-    ZK_HIP(hipMalloc(&work, (n + SCAN_MAX_PARTIALS) * eb));
+    ZK_ALLOC(&work, (n + SCAN_MAX_PARTIALS) * eb);
     uint32_t* partial = work + n * P::W;
     int rc = ZK_OK;
     do {
@@ -351,7 +351,7 @@ static int div_linear_dev_impl(uint64_t n, const void* coeffs, const uint64_t* r
         }
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = fail(ZK_ERR_HIP, "div_linear: kernel failed");
     } while (0);
-    (void)hipFree(work);
+    dev_free_cached(work);
     return rc;
 }
 
@@ -374,7 +374,7 @@ static int is_zero_impl(uint64_t n, const void* x, int* is_zero, hipStream_t st)
     *is_zero = 1;
     if (n == 0) return ZK_OK;
     int* dflag = nullptr;
-    ZK_HIP(hipMalloc(&dflag, sizeof(int)));
+    ZK_ALLOC(&dflag, sizeof(int));
     int flag = 0, rc = ZK_OK;
     do {
         if (hipMemsetAsync(dflag, 0, sizeof(int), st) != hipSuccess) { rc = fail(ZK_ERR_HIP, "hipMemsetAsync failed"); break; }
@@ -383,7 +383,7 @@ static int is_zero_impl(uint64_t n, const void* x, int* is_zero, hipStream_t st)
         if (hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { rc = fail(ZK_ERR_HIP, "is_zero: copy back failed"); break; }
     } while (0);
-    (void)hipFree(dflag);
+    dev_free_cached(dflag);
     *is_zero = flag ? 0 : 1;
     return rc;
 }
@@ -431,7 +431,7 @@ static int poly_eval_impl_dev(uint64_t n, const void* coeffs, const uint64_t* x,
     uint64_t threads = (n + chunk - 1) / chunk;
     unsigned blocks = (unsigned)((threads + 255) / 256);
     uint32_t* dpart = nullptr;
-    ZK_HIP(hipMalloc(&dpart, (size_t)blocks * P::W * 4));
+    ZK_ALLOC(&dpart, (size_t)blocks * P::W * 4);
     std::vector<uint32_t> part((size_t)blocks * P::W);
     int rc = ZK_OK;
     hipLaunchKernelGGL(poly_eval_kernel<P>, dim3(blocks), dim3(256), 0, st, n, chunk, (const uint32_t*)coeffs,
@@ -439,11 +439,45 @@ static int poly_eval_impl_dev(uint64_t n, const void* coeffs, const uint64_t* x,
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(part.data(), dpart, part.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
         rc = fail(ZK_ERR_HIP, "poly_eval: kernel or copy back failed");
-    (void)hipFree(dpart);
+    dev_free_cached(dpart);
     if (rc) return rc;
     Fp<P> acc = fp_zero<P>();
     for (unsigned b = 0; b < blocks; ++b) acc = fp_add<P>(acc, fp_unpack<P>(part.data() + (size_t)b * P::W));
     fp_pack<P>(o, fp_reduce_full<P>(acc));
+    return ZK_OK;
+}
+
+// k evaluations with ONE synchronisation: all kernels go out first (each into its own slice of the partial-sum buffer)
+template <class P>
+static int poly_eval_many_impl(int k, const uint64_t* counts, const void* const* coeffs, const uint64_t* xs, uint64_t* outs, hipStream_t st) {
+    const uint32_t chunk = 32;
+    std::vector<unsigned> blocks(k), first(k);
+    unsigned total = 0;
+    for (int i = 0; i < k; ++i) {
+        blocks[i] = (unsigned)(((counts[i] + chunk - 1) / chunk + 255) / 256);
+        first[i] = total;
+        total += blocks[i];
+    }
+    for (int i = 0; i < k * P::W / 2; ++i) outs[i] = 0;
+    if (total == 0) return ZK_OK;
+    uint32_t* dpart = nullptr;
+    ZK_ALLOC(&dpart, (size_t)total * P::W * 4);
+    std::vector<uint32_t> part((size_t)total * P::W);
+    int rc = ZK_OK;
+    for (int i = 0; i < k; ++i)
+        if (counts[i])
+            hipLaunchKernelGGL(poly_eval_kernel<P>, dim3(blocks[i]), dim3(256), 0, st, counts[i], chunk, (const uint32_t*)coeffs[i],
+                               fp_from_canonical<P>(reinterpret_cast<const uint32_t*>(xs + (size_t)i * (P::W / 2))), dpart + (size_t)first[i] * P::W);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(part.data(), dpart, part.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        rc = fail(ZK_ERR_HIP, "poly_eval: kernel or copy back failed");
+    dev_free_cached(dpart);
+    if (rc) return rc;
+    for (int i = 0; i < k; ++i) {
+        Fp<P> acc = fp_zero<P>();
+        for (unsigned b = 0; b < blocks[i]; ++b) acc = fp_add<P>(acc, fp_unpack<P>(part.data() + (size_t)(first[i] + b) * P::W));
+        fp_pack<P>(reinterpret_cast<uint32_t*>(outs + (size_t)i * (P::W / 2)), fp_reduce_full<P>(acc));
+    }
     return ZK_OK;
 }
 
@@ -452,6 +486,13 @@ static int poly_eval_impl_dev(uint64_t n, const void* coeffs, const uint64_t* x,
 using namespace zkmi;
 
 extern "C" {
+
+int zk_poly_eval_many_dev(int curve, int k, const uint64_t* counts, const void* const* d_coeffs, const uint64_t* xs, uint64_t* outs, void* stream) {
+    if (k < 0 || k > 64) return fail(ZK_ERR_ARG, "poly_eval_many: 0 .. 64 polynomials");
+#define CALL(P) return poly_eval_many_impl<P>(k, counts, d_coeffs, xs, outs, (hipStream_t)stream)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
 
 int zk_vec_axpby_dev(int curve, uint64_t n, const uint64_t* a, const void* d_x, const uint64_t* b, const void* d_y, const uint64_t* c,
                      void* d_out, void* stream) {

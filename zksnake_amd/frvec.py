@@ -223,11 +223,20 @@ class FrOps:
         N.check(N.load().zk_poly_eval_dev(self.cid, n, ptr, N.u64p(self.one(x)), N.u64p(out), None))
         return int.from_bytes(out.tobytes(), "little")
 
+    def d_eval_many(self, jobs):
+        """[(n, device pointer, x)] -> values; one synchronisation for all of them"""
+        k = len(jobs)
+        counts = np.array([j[0] for j in jobs], dtype=np.uint64)
+        ptrs = (N._vp * k)(*[j[1] for j in jobs])
+        xs = np.concatenate([self.one(j[2]) for j in jobs]).reshape(k, 4)
+        outs = np.zeros((k, 4), dtype=np.uint64)
+        N.check(N.load().zk_poly_eval_many_dev(self.cid, k, N.u64p(counts), ptrs, N.u64p(xs), N.u64p(outs), None))
+        return self.ints(outs)
+
     def d_add_at(self, vec, i, value):
-        """vec[i] += value (mod r): one 32-byte round trip"""
-        cur = vec.download(1, i)
-        self.add_at(cur, 0, value)
-        vec.upload(cur, i)
+        """vec[i] += value (mod r) on the device: a one-element launch on the stream, no round trip through the host"""
+        p = vec.ptr(i)
+        N.check(N.load().zk_vec_axpby_dev(self.cid, 1, N.u64p(self.one(1)), p, None, None, N.u64p(self.one(value % self.r)), p, None))
 
     def d_gather(self, n, src_ptr, stride, offset, dst_ptr):
         """dst[i] = src[offset + i * stride]"""

@@ -63,9 +63,10 @@ class Plonk:
         # win (the wider windows the library would pick for the table's size pay only from ~2^20 scalars per MSM)
         return pk.tau_g1.plan(slot, precompute=True, window_bits=16 if pk.n < (1 << 20) else 0)
 
-    def _commit_many(self, jobs):
+    def _commit_many(self, jobs, meanwhile=None):
         """jobs: [(device vector, count, offset)] -> commitments; the MSMs of one round run concurrently on their plans'
-        own streams (the latency-bound reduction of one hides behind the accumulation of the others)"""
+        own streams (the latency-bound reduction of one hides behind the accumulation of the others).
+        meanwhile: host work that does not need the results, done while the GPU runs them."""
         lib, cid = N.load(), self.E.curve.curve_id
         from .._algebra import _point_class
         handles = []
@@ -74,6 +75,8 @@ class Plonk:
             h = self._tau_plan(slot)
             N.check(lib.zk_msm_plan_enqueue(h, count, vec.ptr(offset), 1, 0, 0, N.STREAM_PLAN))
             handles.append(h)
+        if meanwhile is not None:
+            meanwhile()
         points = []
         for h in handles:
             out = np.zeros(N.point_limbs(cid, 1), dtype=np.uint64)
@@ -290,8 +293,13 @@ class Plonk:
         # T = t_lo + X^n t_mid + X^2n t_hi with t_lo += b9 X^n, t_mid += -b9 + b10 X^n, t_hi += -b10: the blinding terms
         # are added on the group side (tau_g1[0] = G, tau_g1[n] = tau^n G)
         G, Gn = pk.tau_g1[0], pk.tau_g1[n]
-        t_lo, t_mid, t_hi = self._commit_many([(t, n, 0), (t, n, n), (t, n + 6, 2 * n)])
-        tau_t = [t_lo + Gn * blind[9], t_mid + G * ((-blind[9]) % r) + Gn * blind[10], t_hi + G * ((-blind[10]) % r)]
+        fixed = []   # the four blinding multiples need the key and the blinding scalars only: computed while the MSMs run
+
+        def blinding_terms():
+            fixed.extend([Gn * blind[9], G * ((-blind[9]) % r) + Gn * blind[10], G * ((-blind[10]) % r)])
+
+        t_lo, t_mid, t_hi = self._commit_many([(t, n, 0), (t, n, n), (t, n + 6, 2 * n)], meanwhile=blinding_terms)
+        tau_t = [t_lo + fixed[0], t_mid + fixed[1], t_hi + fixed[2]]
         for point in tau_t:
             transcript.append(point)
 
@@ -299,10 +307,9 @@ class Plonk:
         zeta = transcript.get_challenge_scalar()
         omega = dev["omega"]
         sc = dev["sigma_coeffs"]
-        za, zb, zc = (V.d_eval(n + 2, w.ptr(), zeta) for w in wires)
-        zs1, zs2 = V.d_eval(n, sc[0].ptr(), zeta), V.d_eval(n, sc[1].ptr(), zeta)
-        zzw = V.d_eval(n + 3, z.ptr(), zeta * omega % r)
-        pi_zeta = V.d_eval(n, pi_c.ptr(), zeta)
+        za, zb, zc, zs1, zs2, zzw, pi_zeta = V.d_eval_many(
+            [(n + 2, w.ptr(), zeta) for w in wires] + [(n, sc[0].ptr(), zeta), (n, sc[1].ptr(), zeta),
+                                                       (n + 3, z.ptr(), zeta * omega % r), (n, pi_c.ptr(), zeta)])
         zeta_n = pow(zeta, n, r)
         zh_zeta = (zeta_n - 1) % r
         l1_zeta = zh_zeta * pow(n * (zeta - 1) % r, -1, r) % r
