@@ -343,6 +343,7 @@ def test_key_file_round_trip_and_pinned_witness(gpu):
     g2 = Groth16(r1cs, "BN254")
     g2._blinding = BLIND
     g2.proving_key, g2.verifying_key = pk, VerifyingKey.from_bytes(vb, "BN254")
+    g2.prepare_prover()   # plans and QAP workspace for a key that did not come from setup()
     assert g2.prove(w[:2], w[2:]).to_bytes() == proof.to_bytes()
     pub, prv = N.ints_to_limbs(w[:2]), N.ints_to_limbs(w[2:])
     assert g2.prove(pub, prv).to_bytes() == proof.to_bytes()

@@ -149,6 +149,24 @@ class Groth16:
             arr.window_range = rng
         return arr.plan(slot, precompute=self.precompute_keys, high_priority=high_priority)
 
+    def prepare_prover(self):
+        """build what the first prove() would otherwise build: the fixed-base MSM plans of the proving key and the QAP's
+        device-resident matrices and workspace.  setup() does this by default; call it after loading a key from bytes
+        (`groth16.proving_key = ProvingKey.from_bytes(...)`) to pay the one-off cost before the first proof.  Not in the
+        reference's API."""
+        assert self.proving_key, "ProvingKey has not been generated"
+        pk = self.proving_key
+        pk.tau_1, pk.tau_2 = _as_array(self.E, pk.tau_1, 1), _as_array(self.E, pk.tau_2, 2)
+        pk.target_1, pk.kdelta_1 = _as_array(self.E, pk.target_1, 1), _as_array(self.E, pk.kdelta_1, 1)
+        for arr, group, slot, hp in ((pk.tau_1, 1, 0, False), (pk.tau_2, 2, 0, True), (pk.tau_1, 1, 1, False), (pk.target_1, 1, 0, False),
+                                     (pk.kdelta_1, 1, 0, False)):
+            if len(arr):
+                self._build_plan(arr, group, slot, hp)
+        n, n_wires = self.qap.a.n_row, self.qap.a.n_col
+        self.qap._device_matrices()
+        self.qap._workspace(n, n_wires)
+        self.qap._qap_stream()
+
     def _start_plan_worker(self, jobs):
         import threading
 
