@@ -125,6 +125,13 @@ int zk_spmv_long_dev(int curve, uint64_t n_long, const void* d_long_rows, const 
  * the division would leave a remainder (the reference raises ValueError there); h is meaningless in that case. */
 int zk_qap_h_dev(int curve, int log_n, void* d_a_u, void* d_b_v, const void* d_c, void* d_h, void* d_work,
                  int* divisible, void* stream);
+/* The same in two steps.  _begin puts the whole chain on the stream and returns; *uv_ready (may be NULL) receives an event,
+ * owned by the library and reused by the next _begin on that stream, that fires once u and v are final (a third of the
+ * way into the chain): MSMs over u and v can sort beside the rest of it (zk_msm_plan_wait_event).  _end copies the
+ * divisibility flag back and synchronises the stream. */
+int zk_qap_h_dev_begin(int curve, int log_n, void* d_a_u, void* d_b_v, const void* d_c, void* d_h, void* d_work, void* stream,
+                       void** uv_ready);
+int zk_qap_h_dev_end(int curve, int log_n, const void* d_work, int* divisible, void* stream);
 
 /* ---- curve groups (ec_bn254 / ec_bls12_381 submodules) ---------------------------------- */
 
@@ -187,6 +194,11 @@ int zk_msm_plan_enqueue(uint64_t handle, uint64_t n_scalars, const void* scalars
 int zk_msm_plan_enqueue_sort(uint64_t handle, uint64_t n_scalars, const void* scalars, int scalars_on_device,
                              int window_first, int window_count, void* stream);
 int zk_msm_plan_enqueue_rest(uint64_t handle, uint64_t after_handle);
+/* the plan's own stream (ZK_STREAM_PLAN) waits for an event of another stream (e.g. zk_qap_h_dev_begin's uv_ready) before
+ * whatever is enqueued on it next */
+int zk_msm_plan_wait_event(uint64_t handle, void* event);
+/* forget a run in flight (sorted only, or complete) without collecting its result: waits for the plan's stream */
+int zk_msm_plan_cancel(uint64_t handle);
 /* The same scalars against a second set of bases (Groth16: <tau_1, v> in G1 and <tau_2, v> in G2): run `handle` on the
  * digits and the sorted entry list of `lender_handle`'s run in flight instead of sorting again.  Both plans must have the
  * same size, window layout, mode and window range (else ZK_ERR_ARG: enqueue normally); finish both as usual.  A general-mode

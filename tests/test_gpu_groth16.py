@@ -358,3 +358,22 @@ def test_key_file_round_trip_and_pinned_witness(gpu):
     bad[off:off + 32] = b"\xff" * 32
     with pytest.raises(N.ZkError, match="Cannot deserialize point"):
         ProvingKey.from_bytes(bytes(bad), "BN254")
+
+
+def test_bad_witness_after_the_early_sorts_leaves_the_prover_usable(gpu):
+    """prove() queues the sorts of <tau_1, u> and <tau_1, v> beside the QAP chain; when the chain then reports a witness that
+    does not satisfy the constraints, those runs are cancelled and the next prove() works"""
+    cv = pyref.BN254
+    n = 1 << 11
+    A, B, C, w, n_col = W.chain_circuit(n, cv.r)
+    g = Groth16(R1CS.from_triplets(A, B, C, n, n_col, 2, "BN254"), "BN254")
+    g._toxic, g._blinding = TOXIC, BLIND
+    g.setup()
+    good = g.prove(w[:2], w[2:])
+    bad = list(w)
+    bad[7] = (bad[7] + 1) % cv.r
+    for _ in range(2):
+        with pytest.raises(ValueError, match="Failed to evaluate with the given witness"):
+            g.prove(bad[:2], bad[2:])
+    again = g.prove(w[:2], w[2:])
+    assert again.to_bytes() == good.to_bytes() and g.verify(again, w[:2])

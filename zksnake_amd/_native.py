@@ -70,6 +70,8 @@ SIGNATURES = {
     "zk_vec_canon_dev": (_i, [_i, _u64, _vp, _vp]),
     "zk_vec_powers_dev": (_i, [_i, _u64, _u64p, _vp, _vp]),
     "zk_qap_h_dev": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_i), _vp]),
+    "zk_qap_h_dev_begin": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
+    "zk_qap_h_dev_end": (_i, [_i, _i, _vp, ctypes.POINTER(_i), _vp]),
     "zk_msm": (_i, [_i, _i, _u64, _u64, _u64p, _u64p, _u64p]),
     "zk_batch_mul": (_i, [_i, _i, _u64, _u64p, _u64p, _i, _u64p]),
     "zk_msm_plan_create": (_i, [_i, _i, _u64, _vp, _i, _i, _i, _u64p]),
@@ -80,6 +82,8 @@ SIGNATURES = {
     "zk_msm_plan_enqueue": (_i, [_u64, _u64, _vp, _i, _i, _i, _vp]),
     "zk_msm_plan_enqueue_sort": (_i, [_u64, _u64, _vp, _i, _i, _i, _vp]),
     "zk_msm_plan_enqueue_rest": (_i, [_u64, _u64]),
+    "zk_msm_plan_wait_event": (_i, [_u64, _vp]),
+    "zk_msm_plan_cancel": (_i, [_u64]),
     "zk_msm_plan_enqueue_shared": (_i, [_u64, _u64, _vp]),
     "zk_msm_plan_finish": (_i, [_u64, _u64p]),
     "zk_msm_plan_windows": (_i, [_u64, ctypes.POINTER(_i), ctypes.POINTER(_i)]),

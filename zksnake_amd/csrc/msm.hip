@@ -114,6 +114,19 @@ int zk_msm_plan_enqueue_rest(uint64_t handle, uint64_t after_handle) {
     return p->enqueue_rest(after);
 }
 
+int zk_msm_plan_wait_event(uint64_t handle, void* event) {
+    MsmPlanBase* p = find_plan(handle);
+    if (!p || !event) return fail(ZK_ERR_ARG, "unknown MSM plan handle or null event");
+    ZK_HIP(hipStreamWaitEvent(p->own_stream, (hipEvent_t)event, 0));
+    return ZK_OK;
+}
+
+int zk_msm_plan_cancel(uint64_t handle) {
+    MsmPlanBase* p = find_plan(handle);
+    if (!p) return fail(ZK_ERR_ARG, "unknown MSM plan handle");
+    return p->cancel();
+}
+
 int zk_msm_plan_enqueue_shared(uint64_t handle, uint64_t lender_handle, void* stream) {
     MsmPlanBase* p = find_plan(handle);
     MsmPlanBase* lender = find_plan(lender_handle);

@@ -1796,6 +1796,13 @@ struct MsmPlan : MsmPlanBase {
         return ZK_OK;
     }
 
+    int cancel() override {
+        std::lock_guard<std::mutex> lock(mu);
+        if ((q_pending || q_sorted) && q_stream) ZK_HIP(hipStreamSynchronize(q_stream));
+        q_pending = q_sorted = false;
+        return ZK_OK;
+    }
+
     int export_sort(SortExport* out) override {
         std::lock_guard<std::mutex> lock(mu);
         if ((!q_pending && !q_sorted) || q_m == 0) return fail(ZK_ERR_ARG, "the lending plan has no run in flight");

@@ -106,6 +106,8 @@ struct MsmPlanBase {
     virtual int enqueue_rest(MsmPlanBase* after) = 0;
     virtual hipEvent_t accumulate_done_event() = 0;
     virtual int finish(uint64_t* out) = 0;
+    // forget a run whose sort (or all of it) is in flight without collecting a result: waits for the stream
+    virtual int cancel() = 0;
     int run(uint64_t n_scalars, const void* scalars, int on_device, int w_first, int w_count, uint64_t* out,
             hipStream_t stream) {
         int rc = enqueue(n_scalars, scalars, on_device, w_first, w_count, stream);

@@ -389,7 +389,9 @@ static int get_twiddles(int curve, int log_n, TwiddleSet* out, hipStream_t strea
 
 static void free_scratch();
 static void free_coset_tables();
+static void free_uv_events();
 static void free_twiddles() {
+    free_uv_events();
     std::lock_guard<std::mutex> lock(g_tw_mutex);
     for (auto& kv : g_twiddles) {
         (void)hipFree(kv.second.fwd);
@@ -670,9 +672,30 @@ __global__ void qap_quotient_kernel(uint64_t n, const uint32_t* __restrict__ u, 
     store_fr<P>(out + i * P::W, fp_reduce_full<P>(fp_mul<P>(d, z_r2)));
 }
 
+static std::mutex g_uv_mutex;
+static std::map<hipStream_t, hipEvent_t> g_uv_events;  // one "u and v are final" event per stream (zk_qap_h_dev_begin)
+
+static int uv_event_for(hipStream_t stream, hipEvent_t* out) {
+    std::lock_guard<std::mutex> lock(g_uv_mutex);
+    auto it = g_uv_events.find(stream);
+    if (it == g_uv_events.end()) {
+        hipEvent_t e = nullptr;
+        ZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        it = g_uv_events.emplace(stream, e).first;
+    }
+    *out = it->second;
+    return ZK_OK;
+}
+static void free_uv_events() {
+    std::lock_guard<std::mutex> lock(g_uv_mutex);
+    for (auto& kv : g_uv_events) (void)hipEventDestroy(kv.second);
+    g_uv_events.clear();
+}
+
+// divisible == nullptr: enqueue only (zk_qap_h_dev_begin); uv_ready (optional) is recorded once u and v are final
 template <class P>
 static int qap_h_dev_impl(int curve, int log_n, uint32_t* a_u, uint32_t* b_v, const uint32_t* c, uint32_t* h,
-                          uint32_t* work, int* divisible, hipStream_t stream) {
+                          uint32_t* work, int* divisible, hipStream_t stream, hipEvent_t uv_ready = nullptr) {
     if (log_n > P::TWO_ADICITY) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
     const uint64_t n = 1ull << log_n;
     const size_t eb = P::W * 4;
@@ -688,6 +711,7 @@ static int qap_h_dev_impl(int curve, int log_n, uint32_t* a_u, uint32_t* b_v, co
     hipLaunchKernelGGL(qap_eval_check_kernel<P>, dim3(blocks), dim3(256), 0, stream, n, a_u, b_v, c, dflag);
     if ((rc = ntt_dev_impl<P>(curve, 1, log_n, a_u, stream))) return rc;  // u
     if ((rc = ntt_dev_impl<P>(curve, 1, log_n, b_v, stream))) return rc;  // v
+    if (uv_ready) ZK_HIP(hipEventRecord(uv_ready, stream));
     ZK_HIP(hipMemcpyAsync(W0, c, n * eb, hipMemcpyDeviceToDevice, stream));
     if ((rc = ntt_dev_impl<P>(curve, 1, log_n, W0, stream))) return rc;   // w
     hipLaunchKernelGGL(coset_mul_kernel<P>, dim3(blocks), dim3(256), 0, stream, a_u, U1, n, ct.lo, ct.hi);
@@ -705,6 +729,7 @@ static int qap_h_dev_impl(int curve, int log_n, uint32_t* a_u, uint32_t* b_v, co
     if ((rc = ntt_dev_impl<P>(curve, 1, log_n, U1, stream))) return rc;
     hipLaunchKernelGGL(coset_mul_kernel<P>, dim3(blocks), dim3(256), 0, stream, U1, h, n, ct.lo_inv, ct.hi_inv);
     ZK_HIP(hipGetLastError());
+    if (!divisible) return ZK_OK;
     int flag = 0;
     ZK_HIP(hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, stream));
     ZK_HIP(hipStreamSynchronize(stream));
@@ -754,6 +779,29 @@ int zk_qap_h_dev(int curve, int log_n, void* d_a_u, void* d_b_v, const void* d_c
 #define CALL(P) return qap_h_dev_impl<P>(curve, log_n, (uint32_t*)d_a_u, (uint32_t*)d_b_v, (const uint32_t*)d_c, (uint32_t*)d_h, (uint32_t*)d_work, divisible, (hipStream_t)stream)
     ZK_DISPATCH_FR(curve, CALL);
 #undef CALL
+}
+
+int zk_qap_h_dev_begin(int curve, int log_n, void* d_a_u, void* d_b_v, const void* d_c, void* d_h, void* d_work, void* stream, void** uv_ready) {
+    hipEvent_t ev = nullptr;
+    if (uv_ready) {
+        int rc = uv_event_for((hipStream_t)stream, &ev);
+        if (rc) return rc;
+        *uv_ready = (void*)ev;
+    }
+#define CALL(P) return qap_h_dev_impl<P>(curve, log_n, (uint32_t*)d_a_u, (uint32_t*)d_b_v, (const uint32_t*)d_c, (uint32_t*)d_h, (uint32_t*)d_work, nullptr, (hipStream_t)stream, ev)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_qap_h_dev_end(int curve, int log_n, const void* d_work, int* divisible, void* stream) {
+    if (curve != ZK_CURVE_BN254 && curve != ZK_CURVE_BLS12_381) return fail(ZK_ERR_ARG, "unknown curve");
+    if (log_n < 0 || log_n > 32) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
+    const int* dflag = reinterpret_cast<const int*>(reinterpret_cast<const uint32_t*>(d_work) + ((size_t)3 << log_n) * 8);  // both scalar fields: 8 words
+    int flag = 0;
+    ZK_HIP(hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    ZK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    *divisible = flag ? 0 : 1;
+    return ZK_OK;
 }
 
 int zk_spmv_dev(int curve, uint64_t n_rows, const void* d_row_ptr, const void* d_cols, const void* d_vals,

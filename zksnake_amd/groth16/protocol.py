@@ -197,7 +197,8 @@ class Groth16:
                 if isinstance(arr, PointArray) and arr.window_range is None:
                     arr.release()
 
-    def _enqueue_msm(self, bases, group, d_scalars, count, slot=0, high_priority=False, share_sort_of=None, sort_only=False):
+    def _enqueue_msm(self, bases, group, d_scalars, count, slot=0, high_priority=False, share_sort_of=None, sort_only=False,
+                     wait_event=None):
         """start <bases[:count], scalars> (scalars already in HBM) on the plan's own stream; with sharding only
         this rank's windows.  Returns (array, handle); handle None = this rank has no window of that MSM.
         sort_only: digits and sort only -- the accumulate kernel and the reduction follow with _enqueue_rest."""
@@ -213,6 +214,8 @@ class Groth16:
                 return arr, None
             arr.window_range = (first, cnt)
         handle = arr.plan(slot, precompute=self.precompute_keys, high_priority=high_priority)
+        if wait_event is not None:
+            N.check(lib.zk_msm_plan_wait_event(handle, wait_event))   # the scalars are still being produced on another stream
         if share_sort_of is not None and count == len(arr) and not os.environ.get("ZKMI_NO_SHARED_SORT"):
             # <tau_1, v> is already in flight with the same scalars: B2 = <tau_2, v> reuses its digits and sorted entries
             if lib.zk_msm_plan_enqueue_shared(handle, share_sort_of, N.STREAM_PLAN) == N.ZK_OK:
@@ -283,11 +286,23 @@ class Groth16:
             if n_priv > 0:
                 pk.kdelta_1, early["k"] = self._enqueue_msm(pk.kdelta_1, 1, d_witness.ptr + 32 * n_pub, n_priv)
 
+        ordered = not os.environ.get("ZKMI_UNORDERED_MSMS")
+        n_rows = self.qap.a.n_row
+
+        def start_uv_sorts(event, d_u, d_v):
+            # u and v are final a third of the way into the QAP chain: the sorts of <tau_1, v> and <tau_1, u> run beside
+            # the rest of it instead of in a phase of their own afterwards
+            pk.tau_1, early["v1"] = self._enqueue_msm(pk.tau_1, 1, d_v.ptr, min(n_rows, len(pk.tau_1)), slot=1, sort_only=True, wait_event=event)
+            pk.tau_1, early["u"] = self._enqueue_msm(pk.tau_1, 1, d_u.ptr, min(n_rows, len(pk.tau_1)), slot=0, sort_only=True, wait_event=event)
+
         try:
-            res = self.qap.evaluate_witness_device(witness, after_upload=start_witness_msm)
+            res = self.qap.evaluate_witness_device(witness, after_upload=start_witness_msm, after_uv=start_uv_sorts if ordered else None)
         except ValueError as exc:
-            if early.get("k") is not None:  # drain the run in flight: the plan accepts one at a time
+            if early.get("k") is not None:  # drain the runs in flight: a plan accepts one at a time
                 self._finish_msm(early["k"], 1)
+            for key in ("v1", "u"):
+                if early.get(key) is not None:
+                    N.check(N.load().zk_msm_plan_cancel(early[key]))
             raise ValueError("Failed to evaluate with the given witness") from exc
 
         t_qap = time.perf_counter()
@@ -297,11 +312,11 @@ class Groth16:
         # them starve.  So the three sorts go first, side by side, and the accumulate kernels run one after the other,
         # the G2 one (three times the work of a G1 one, and the longest reduction tail) at the head: every reduction but
         # the last overlaps the next plan's accumulate kernel.
-        ordered = not os.environ.get("ZKMI_UNORDERED_MSMS")
-        pk.tau_1, h_v1 = self._enqueue_msm(pk.tau_1, 1, res.v.ptr, min(n, len(pk.tau_1)), slot=1, sort_only=ordered)
         if ordered:
-            pk.tau_1, h_u = self._enqueue_msm(pk.tau_1, 1, res.u.ptr, min(n, len(pk.tau_1)), slot=0, sort_only=True)
+            h_v1, h_u = early.get("v1"), early.get("u")   # sorts enqueued beside the QAP chain
             pk.target_1, h_h = self._enqueue_msm(pk.target_1, 1, res.h.ptr, min(n, len(pk.target_1)), sort_only=True)
+        else:
+            pk.tau_1, h_v1 = self._enqueue_msm(pk.tau_1, 1, res.v.ptr, min(n, len(pk.tau_1)), slot=1)
         pk.tau_2, h_v2 = self._enqueue_msm(pk.tau_2, 2, res.v.ptr, min(n, len(pk.tau_2)), high_priority=True, share_sort_of=h_v1)
         if ordered:
             self._enqueue_rest(h_v1, h_v2)

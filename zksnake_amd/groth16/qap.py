@@ -80,11 +80,13 @@ class QAP:
             self._stream = st
         return self._stream
 
-    def evaluate_witness_device(self, witness, after_upload=None) -> DeviceQapResult:
+    def evaluate_witness_device(self, witness, after_upload=None, after_uv=None) -> DeviceQapResult:
         """witness: list of ints or (n_col, 4) uint64 limbs.  Raises ValueError when the witness does
         not satisfy the constraints (non-zero remainder), like the reference.  The returned buffers belong
         to this QAP object and are overwritten by the next call.  `after_upload(witness_buffer)` is called once the
-        canonical witness is resident in HBM, before the transform chain is enqueued."""
+        canonical witness is resident in HBM, before the transform chain is enqueued.  `after_uv(event, u, v)` is called
+        with the chain in flight: `event` fires when the coefficient vectors u and v (device buffers) are final, a third
+        of the way into the chain, so that work that needs only them can be queued behind it."""
         lib = N.ensure_gpu()
         cid = self._curve_id()
         n = self.a.n_row
@@ -116,7 +118,14 @@ class QAP:
         for mat, dst in zip(self._device_matrices(), (ws["a"], ws["b"], ws["c"])):
             mat.apply(ws["w"].ptr, dst.ptr, st)
         ok = N._i(0)
-        N.check(lib.zk_qap_h_dev(cid, log_n, ws["a"].ptr, ws["b"].ptr, ws["c"].ptr, ws["h"].ptr, ws["work"].ptr, ok, st))
+        if after_uv is None:
+            N.check(lib.zk_qap_h_dev(cid, log_n, ws["a"].ptr, ws["b"].ptr, ws["c"].ptr, ws["h"].ptr, ws["work"].ptr, ok, st))
+        else:
+            event = N._vp()
+            N.check(lib.zk_qap_h_dev_begin(cid, log_n, ws["a"].ptr, ws["b"].ptr, ws["c"].ptr, ws["h"].ptr, ws["work"].ptr, st,
+                                           N.ctypes.byref(event)))
+            after_uv(event, ws["a"], ws["b"])
+            N.check(lib.zk_qap_h_dev_end(cid, log_n, ws["work"].ptr, ok, st))
         if not ok.value:
             raise ValueError("(U * V - W) did not divided by Z to zero")
         return DeviceQapResult(n, ws["a"], ws["b"], ws["h"], ws["w"])
