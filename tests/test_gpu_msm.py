@@ -565,3 +565,37 @@ def test_two_step_enqueue_orders_the_accumulate_kernels(gpu, flags):
     finally:
         for h in plans:
             N.check(gpu.zk_msm_plan_destroy(h))
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+def test_split_scalar_plan_on_the_decomposition_corner_cases(gpu, name, cid):
+    """scalars at and around lambda, r - lambda, the thirds of r, powers of two and their negatives: the places where the
+    short-lattice rounding of the split-scalar digits kernel changes sign or carries"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("gen_glv_params", os.path.join(os.path.dirname(__file__), "..", "tools", "gen_glv_params.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    cs = G.constants("Bn254" if cid == 0 else "Bls381")
+    cv = pyref.curve_by_name(name)
+    r, lam = cv.r, cs["lam"]
+    vals = [0, 1, 2, r - 1, r - 2, r // 2, r // 2 + 1, lam, lam + 1, lam - 1, r - lam, r - lam + 1, (r - 1) // 3, 2 * (r - 1) // 3,
+            lam * lam % r, (lam * lam + 1) % r, cs["a1"] % r, (-cs["b1"]) % r, cs["a2"] % r, cs["b2"] % r]
+    vals += [(1 << b) % r for b in range(0, 256, 7)] + [(r - (1 << b)) % r for b in range(0, 254, 9)]
+    n = len(vals)
+    _, bases = oracle_bases(cid, 1, n, 123)
+    sc = N.ints_to_limbs(vals, 4)
+    exp = corc.msm(cid, 1, sc, bases, threads=8)
+    for flags in (0, N.MSM_NO_GLV):
+        for c in (0, 16, 13):
+            h = N._u64(0)
+            N.check(gpu.zk_msm_plan_create(cid, 1, n, bases.ctypes.data, 0, flags, c, h))
+            out = np.zeros(N.point_limbs(cid, 1), dtype=np.uint64)
+            N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, 0, 0, N.u64p(out), None))
+            N.check(gpu.zk_msm_plan_destroy(h))
+            assert (out == exp).all(), (flags, c)
+    # every scalar alone against one base: a wrong half-scalar cannot hide in a sum
+    for i in range(n):
+        one = np.zeros(N.point_limbs(cid, 1), dtype=np.uint64)
+        N.check(gpu.zk_msm(cid, 1, 1, 1, N.u64p(sc[i:i + 1].copy()), N.u64p(bases[i:i + 1].copy()), N.u64p(one)))
+        assert (one == corc.msm(cid, 1, sc[i:i + 1], bases[i:i + 1], threads=1)).all(), vals[i]
