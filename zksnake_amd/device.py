@@ -49,7 +49,8 @@ class DeviceBuffer:
 
 
 class PinnedArray:
-    """page-locked host memory viewed as a numpy array (`.array`): staging for vectors that cross the link every proof"""
+    """page-locked host memory viewed as a numpy array (`.array`): staging for vectors that cross the link every proof.
+    Views of `.array` keep the allocation alive; `free()` releases it (do not use views afterwards)."""
 
     def __init__(self, shape, dtype=np.uint64):
         lib = N.ensure_gpu()
@@ -58,6 +59,7 @@ class PinnedArray:
         N.check(lib.zk_host_alloc(self.nbytes, ctypes.byref(ptr)))
         self.ptr = ptr.value
         raw = (ctypes.c_uint8 * max(1, self.nbytes)).from_address(self.ptr)
+        raw._owner = self  # views of the array keep the allocation alive: `PinnedArray(shape).array` alone is safe to hold
         self.array = np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def free(self):
