@@ -65,6 +65,8 @@ class QAP:
         """device buffers reused across proofs (hipMalloc / hipFree are synchronous and slow)"""
         key = (n, n_col)
         if self._ws is None or self._ws[0] != key:
+            if self._ws is not None:
+                self._ws[1]["w_host"].free()   # page-locked staging of the previous size
             eb = 32
             self._ws = (key, dict(w=DeviceBuffer(n_col * eb), a=DeviceBuffer(n * eb), b=DeviceBuffer(n * eb),
                                   c=DeviceBuffer(n * eb), h=DeviceBuffer(n * eb), work=DeviceBuffer(4 * n * eb),
