@@ -47,6 +47,27 @@ extern "C" {
 /* ---- lifecycle ------------------------------------------------------------------------- */
 
 int zk_init(int device);            /* select the HIP device for this process; ZK_ERR_HIP when no GPU */
+
+/* Hardware queues.  A proof keeps seven HIP streams busy; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware
+ * queues (4 by default) and streams that share a queue run one after the other (~ +1 ms per Groth16 proof at 2^20).  The
+ * variable is read once, when the HIP runtime starts (the process's first HIP call).  zk_init / zk_init_ex /
+ * zk_hw_queues_prepare therefore set GPU_MAX_HW_QUEUES=12 BEFORE the library's first HIP call when the caller has not set
+ * it and the runtime is not running yet (the reference has nothing like it: its prover is single-threaded CPU code behind
+ * the GIL, src/lib.rs:6-185).  The status says what happened:
+ *   ZK_QUEUES_SET_BY_LIBRARY  the library put the setting in place in time;
+ *   ZK_QUEUES_CALLER          GPU_MAX_HW_QUEUES was already in the environment and was left alone (*queues = its value);
+ *   ZK_QUEUES_TOO_LATE        the runtime was already running without the setting (e.g. torch touched the GPU before the
+ *                             first zk_ call): results are unaffected, concurrent streams may serialise.  Call
+ *                             zk_hw_queues_prepare() (no HIP call inside) right after loading the library, or export the
+ *                             variable yourself, to avoid it.
+ * The decision is taken once per process; later calls return the same status. */
+#define ZK_QUEUES_SET_BY_LIBRARY 0
+#define ZK_QUEUES_CALLER 1
+#define ZK_QUEUES_TOO_LATE 2
+int zk_hw_queues_prepare(int* queues /* may be NULL; 0 = runtime default */);
+int zk_init_ex(int device, int* queue_status, int* queues);   /* zk_init + the status above (either pointer may be NULL) */
+/* test aid: one wave that spins for `microseconds` on `stream` (used to observe whether streams overlap) */
+int zk_debug_spin_dev(void* stream, uint64_t microseconds);
 int zk_shutdown(void);              /* free cached twiddle tables and workspaces */
 int zk_device_count(void);          /* number of visible HIP devices (0 without a GPU; never fails) */
 const char* zk_last_error(void);
@@ -59,6 +80,9 @@ int zk_dev_free(void* d_ptr);
 int zk_dev_upload(void* d_dst, const void* h_src, uint64_t bytes);
 int zk_dev_download(void* h_dst, const void* d_src, uint64_t bytes);
 int zk_dev_memset(void* d_dst, int value, uint64_t bytes);
+/* the same, ordered on `stream` (NULL = default stream): zk_dev_memset runs on the legacy default stream, which does not
+ * synchronise with the non-blocking streams of zk_stream_create */
+int zk_dev_memset_async(void* d_dst, int value, uint64_t bytes, void* stream);
 int zk_dev_synchronize(void);
 /* page-locked host memory: a witness marshalled into it (and results copied out of it) moves at the link rate instead of
  * through the runtime's staging copies (32 MB of witness: ~0.6 ms against 2-3 ms from pageable memory) */

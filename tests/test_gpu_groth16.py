@@ -225,6 +225,47 @@ def test_groth16_from_circom(gpu):
     assert r1cs.solve_wires({2: 1, 3: 2, 4: 3}) == pub + priv
 
 
+def test_groth16_from_circom_with_hints(gpu):
+    """the reference's examples/example_bitify_circom.py in the same shape: Num2Bits(256) from its circom files, 256 bit
+    hints through constraint_system.unsafe_assign, solve from main.in, compile, generate_witness, setup / prove / verify"""
+    import os
+    from zksnake_amd.arithmetization import Var
+    folder = os.path.join(os.path.dirname(__file__), "golden")
+    r1cs = R1CS.from_file(
+        folder + "/num2bits.r1cs", folder + "/num2bits.sym"
+    )
+
+    def hint(i):
+        return lambda **k: (k["main.in"] >> i) & 1
+
+    for i in range(256):
+        r1cs.constraint_system.unsafe_assign(
+            Var(f"main.out[{i}]"), hint(i), ("main.in", )
+        )
+
+    solution = r1cs.constraint_system.solve(
+        {
+            "main.in": 0xDEADF00D,
+        }
+    )
+
+    r1cs.compile()
+
+    pub, priv = r1cs.generate_witness(solution)
+
+    groth16 = Groth16(r1cs)
+    groth16.setup()
+
+    proof = groth16.prove(pub, priv)
+
+    assert groth16.verify(proof, pub)
+    # beyond the example: the witness satisfies the file's matrices, every wire is public here, a flipped bit is rejected
+    assert r1cs.is_sat(pub, priv) and priv == []
+    forged = list(pub)
+    forged[1] ^= 1
+    assert not groth16.verify(proof, forged)
+
+
 def _sharded_prove_worker(rank, world, port, curve, log_n, q, backend="gloo"):
     """one rank of a window-sharded prove; with gloo all ranks share the box's single GPU, with nccl (= RCCL) every rank
     owns GPU `rank` and the partial points are gathered on the device"""
@@ -375,5 +416,62 @@ def test_bad_witness_after_the_early_sorts_leaves_the_prover_usable(gpu):
     for _ in range(2):
         with pytest.raises(ValueError, match="Failed to evaluate with the given witness"):
             g.prove(bad[:2], bad[2:])
+    again = g.prove(w[:2], w[2:])
+    assert again.to_bytes() == good.to_bytes() and g.verify(again, w[:2])
+
+
+def test_any_failure_half_way_through_prove_cancels_the_runs_in_flight(gpu, monkeypatch):
+    """round-2 advisor finding: only ValueError drained the early runs; a ZkError (allocation failure, HIP error) or any
+    other exception between the first enqueue and the last finish left plans with a run in flight and every later prove()
+    on the key failed.  Here the failure is injected at three places: right after the QAP (sorts and the witness MSM in
+    flight), after every MSM is enqueued, and in the middle of the finishes."""
+    cv = pyref.BN254
+    n = 1 << 11
+    A, B, C, w, n_col = W.chain_circuit(n, cv.r)
+    g = Groth16(R1CS.from_triplets(A, B, C, n, n_col, 2, "BN254"), "BN254")
+    g._toxic, g._blinding = TOXIC, BLIND
+    g.setup()
+    good = g.prove(w[:2], w[2:])
+
+    class Boom(Exception):
+        pass
+
+    real_rest, real_finish = Groth16._enqueue_rest, Groth16._finish_msm
+    calls = {"rest": 0, "finish": 0}
+
+    def rest_fails_first(handle, after):
+        calls["rest"] += 1
+        if calls["rest"] == 1:
+            raise N.ZkError(N.ZK_ERR_HIP, "injected: out of memory")
+        return real_rest(handle, after)
+
+    monkeypatch.setattr(Groth16, "_enqueue_rest", staticmethod(rest_fails_first))
+    with pytest.raises(N.ZkError, match="injected"):
+        g.prove(w[:2], w[2:])
+    assert g._live == []
+    assert g.prove(w[:2], w[2:]).to_bytes() == good.to_bytes()
+
+    def rest_fails_last(handle, after):
+        calls["rest"] += 1
+        real_rest(handle, after)
+        if calls["rest"] % 3 == 0:
+            raise Boom("injected after the last enqueue")
+
+    calls["rest"] = 0
+    monkeypatch.setattr(Groth16, "_enqueue_rest", staticmethod(rest_fails_last))
+    with pytest.raises(Boom):
+        g.prove(w[:2], w[2:])
+    monkeypatch.setattr(Groth16, "_enqueue_rest", staticmethod(real_rest))
+
+    def finish_fails_third(self, handle, group):
+        calls["finish"] += 1
+        if calls["finish"] == 3:
+            raise KeyboardInterrupt
+        return real_finish(self, handle, group)
+
+    monkeypatch.setattr(Groth16, "_finish_msm", finish_fails_third)
+    with pytest.raises(KeyboardInterrupt):
+        g.prove(w[:2], w[2:])
+    monkeypatch.setattr(Groth16, "_finish_msm", real_finish)
     again = g.prove(w[:2], w[2:])
     assert again.to_bytes() == good.to_bytes() and g.verify(again, w[:2])

@@ -67,10 +67,13 @@ def test_msm_length_rules(gpu):
 
 @pytest.mark.parametrize("flags", [0, N.MSM_NO_GLV])
 @pytest.mark.parametrize("name,cid", CURVES)
-@pytest.mark.parametrize("c", [4, 7, 11, 13, 16])
+@pytest.mark.parametrize("c", [2, 3, 4, 7, 11, 13, 16])
 def test_msm_window_sizes_and_sharding(gpu, name, cid, c, flags):
     """every window width gives the same point, with the scalars split by the endomorphism (the default for general G1
-    plans: 2n entries in windows over 128 bits) and without; partial results of disjoint window ranges add up"""
+    plans: 2n entries in windows over 128 bits) and without; partial results of disjoint window ranges add up.
+    Two-bit windows take one window more than ceil(bits / 2): the bias leaves only a third of the range above a positive
+    value, and BLS12-381 half-scalars reach 0.673 * 2^127, its r 0.453 * 2^256 (round-2 advisor finding: ~0.9 % of random
+    scalars overflowed the top digit of a split-scalar plan; the plain windows of BLS12-381 had the same hole)"""
     grp, cv = 1, pyref.curve_by_name(name)
     n = 3000
     _, bases = oracle_bases(cid, grp, n, 70)
@@ -85,7 +88,7 @@ def test_msm_window_sizes_and_sharding(gpu, name, cid, c, flags):
         N.check(gpu.zk_msm_plan_windows(h, cb, nw))
         N.check(gpu.zk_msm_plan_entries(h, ent))
         assert ent.value == (n if flags else 2 * n)
-        assert cb.value == c and nw.value * c >= (cv.r.bit_length() + 1 if flags else 128) and (nw.value - 1) * c < (256 if flags else 128)
+        assert cb.value == c and nw.value == -(-(cv.r.bit_length() + 1 if flags else 128) // c) + (1 if c == 2 else 0)
         lc, ln = N._i(0), N._i(0)
         N.check(gpu.zk_msm_window_layout(cid, grp, n, flags, c, lc, ln))
         assert (lc.value, ln.value) == (cb.value, nw.value)
@@ -599,3 +602,43 @@ def test_split_scalar_plan_on_the_decomposition_corner_cases(gpu, name, cid):
         one = np.zeros(N.point_limbs(cid, 1), dtype=np.uint64)
         N.check(gpu.zk_msm(cid, 1, 1, 1, N.u64p(sc[i:i + 1].copy()), N.u64p(bases[i:i + 1].copy()), N.u64p(one)))
         assert (one == corc.msm(cid, 1, sc[i:i + 1], bases[i:i + 1], threads=1)).all(), vals[i]
+
+
+def test_point_array_plan_cache_follows_the_window_layout(gpu):
+    """PointArray.plan() caches per (slot, mode); a later call with another window width, or after window_range changed,
+    must not get the old plan back (round-2 advisor finding) -- and the results stay the same point"""
+    from zksnake_amd._algebra import PointArray
+    cid, grp, n = 0, 1, 700
+    cv = pyref.BN254
+    _, bases = oracle_bases(cid, grp, n, 31)
+    _, sc = rand_scalars(n, cv.r, 32)
+    exp = corc.msm(cid, grp, sc, bases, threads=8)
+    arr = PointArray(cid, grp, bases)
+
+    def run(h, first=0, count=0):
+        out = np.zeros(N.point_limbs(cid, grp), dtype=np.uint64)
+        N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, first, count, N.u64p(out), None))
+        return out
+
+    def windows(h):
+        c, nw = N._i(0), N._i(0)
+        N.check(gpu.zk_msm_plan_windows(h, c, nw))
+        return c.value, nw.value
+
+    h0 = arr.plan(0, precompute=True, window_bits=9)
+    assert windows(h0)[0] == 9 and (run(h0) == exp).all()
+    assert arr.plan(0, precompute=True) == h0                     # 0 = "whatever the plans have"
+    h1 = arr.plan(1, precompute=True, window_bits=9)              # a clone of the same layout
+    assert h1 != h0 and windows(h1) == windows(h0)
+    h2 = arr.plan(0, precompute=True, window_bits=12)             # another width: both slots are rebuilt
+    assert windows(h2)[0] == 12 and (run(h2) == exp).all()
+    assert windows(arr.plan(1, precompute=True))[0] == 12
+    # a window range (a sharded rank's share): the full-range plans go, the partial results add up
+    from zksnake_amd.parallel import sum_points
+    nw = windows(h2)[1]
+    parts = []
+    for first, count in ((0, nw // 2), (nw // 2, nw - nw // 2)):
+        arr.window_range = (first, count)
+        parts.append(run(arr.plan(0, precompute=True, window_bits=12), first, count))
+    assert (sum_points(cid, grp, parts) == exp).all()
+    arr.release()

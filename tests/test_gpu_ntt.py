@@ -97,6 +97,65 @@ def test_divide_by_vanishing(gpu, name, cid, n, ln):
     assert flag.value == (0 if er else 1)
 
 
+def _ntt_dev_roundtrip(gpu, cid, a, log_n):
+    """forward and inverse transform of `a` on the device: (forward, inverse-of-forward)"""
+    import ctypes
+    d = ctypes.c_void_p()
+    N.check(gpu.zk_dev_alloc(a.nbytes, ctypes.byref(d)))
+    try:
+        N.check(gpu.zk_dev_upload(d, a.ctypes.data, a.nbytes))
+        N.check(gpu.zk_ntt_dev(cid, 0, log_n, d, None))
+        fwd = np.empty_like(a)
+        N.check(gpu.zk_dev_download(fwd.ctypes.data, d, a.nbytes))
+        N.check(gpu.zk_ntt_dev(cid, 1, log_n, d, None))
+        back = np.empty_like(a)
+        N.check(gpu.zk_dev_download(back.ctypes.data, d, a.nbytes))
+    finally:
+        gpu.zk_dev_free(d)
+    return fwd, back
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
+@pytest.mark.parametrize("log_n", [17, 20, 22])
+def test_ntt_three_pass_sizes_match_oracle_elementwise(gpu, name, cid, log_n):
+    """the 3-pass plan (2^17 .. 2^24: BASELINE config 3 and every full-size proof) element by element against the CPU
+    oracle, forward and inverse (round-2 verdict: only spot values were checked above 2^16)"""
+    n = 1 << log_n
+    a = rand_limbs(n, 300 + log_n)   # below 2^252 < r for both fields
+    fwd, back = _ntt_dev_roundtrip(gpu, cid, a, log_n)
+    assert (fwd == corc.ntt(cid, a, threads=8)).all()
+    assert (back == a).all()
+    # the inverse transform of fresh data, on its own
+    import ctypes
+    d = ctypes.c_void_p()
+    N.check(gpu.zk_dev_alloc(a.nbytes, ctypes.byref(d)))
+    try:
+        N.check(gpu.zk_dev_upload(d, a.ctypes.data, a.nbytes))
+        N.check(gpu.zk_ntt_dev(cid, 1, log_n, d, None))
+        inv = np.empty_like(a)
+        N.check(gpu.zk_dev_download(inv.ctypes.data, d, a.nbytes))
+    finally:
+        gpu.zk_dev_free(d)
+    assert (inv == corc.ntt(cid, a, inverse=True, threads=8)).all()
+
+
+def test_ntt_four_pass_size_2_25(gpu):
+    """2^25 is the first size with a 4-pass plan (ntt_dev_impl: ceil(25 / 8) passes): element-wise against the CPU oracle,
+    round trip, and the two spot values that are plain sums"""
+    cid, cv, log_n = 0, pyref.BN254, 25
+    n = 1 << log_n
+    a = rand_limbs(n, 25)
+    fwd, back = _ntt_dev_roundtrip(gpu, cid, a, log_n)
+    assert (back == a).all()
+    assert (fwd == corc.ntt(cid, a, threads=16)).all()
+    # out[0] = sum a_j, out[n/2] = alternating sum: column sums of the 64-bit limbs as Python integers
+    def total(x):
+        return sum(int(x[:, k].astype(object).sum()) << (64 * k) for k in range(4))
+    r = cv.r
+    assert N.limbs_to_ints(fwd[0:1])[0] == total(a) % r
+    assert N.limbs_to_ints(fwd[n // 2:n // 2 + 1])[0] == (total(a[0::2]) - total(a[1::2])) % r
+
+
 def test_ntt_2_22_properties(gpu):
     """BASELINE config 3 size: round trip, linearity, and spot evaluation against Horner"""
     import ctypes
@@ -201,3 +260,24 @@ def test_spmv_long_rows(gpu, name, cid):
     for r, c, v in trip:
         exp[c] = (exp[c] + v * x[r]) % cv.r
     assert N.limbs_to_ints(out_t.download((n_col, 4))) == exp
+
+
+def test_spmv_of_an_empty_matrix_clears_the_output_on_the_given_stream(gpu):
+    """a matrix without entries: the output is cleared with a memset ordered on the caller's (non-blocking) stream, not
+    on the legacy default stream (round-2 advisor finding)"""
+    import ctypes
+    from zksnake_amd.device import DeviceBuffer
+    from zksnake_amd.spmv import DeviceCsr
+    n_row = 1 << 16
+    csr = DeviceCsr(0, np.zeros(n_row + 1, dtype=np.uint32), np.zeros(0, dtype=np.uint32), np.zeros((0, 4), dtype=np.uint64))
+    st = ctypes.c_void_p()
+    N.check(gpu.zk_stream_create(0, ctypes.byref(st)))
+    try:
+        out = DeviceBuffer.from_numpy(np.full((n_row, 4), 9, dtype=np.uint64))
+        dw = DeviceBuffer.from_numpy(np.ones((4, 4), dtype=np.uint64))
+        N.check(gpu.zk_debug_spin_dev(st, 2000))     # the clear must queue up behind work already on the stream
+        csr.apply(dw.ptr, out.ptr, st)
+        N.check(gpu.zk_stream_synchronize(st))
+        assert not out.download((n_row, 4)).any()
+    finally:
+        N.check(gpu.zk_stream_destroy(st))

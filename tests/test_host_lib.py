@@ -48,6 +48,52 @@ def test_no_gpu_fails_loudly(lib):
         N.ensure_gpu()
 
 
+def _queue_probe(code, env_extra):
+    """run `code` in a fresh interpreter (the decision is taken once per process) and return its stdout lines"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "ZKMI_TEST_RUNTIME_STARTED")}
+    env.update(env_extra)
+    env["PYTHONPATH"] = ROOT
+    res = subprocess.run([sys.executable, "-W", "always", "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    return res.stdout.split(), res.stderr
+
+
+_QUEUE_CODE = """
+import ctypes
+{first}
+from zksnake_amd import _native as N
+lib = N.load()
+{second}
+q = ctypes.c_int(-1)
+st = lib.zk_hw_queues_prepare(ctypes.byref(q))
+libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p
+st2, q2 = ctypes.c_int(-1), ctypes.c_int(-1)
+rc = lib.zk_init_ex(0, ctypes.byref(st2), ctypes.byref(q2))
+print(st, q.value, (libc.getenv(b"GPU_MAX_HW_QUEUES") or b"-").decode(), N.queue_status, st2.value, q2.value)
+"""
+
+
+@pytest.mark.parametrize("order", ["torch_first", "lib_first"])
+def test_hw_queues_are_set_by_the_library_in_either_import_order(order):
+    """GPU_MAX_HW_QUEUES is put in place by the C library (zk_hw_queues_prepare / zk_init), not by a Python import side
+    effect: unset -> the library sets 12 before its first HIP call, whichever of torch and the library is imported first
+    (importing torch does not start the HIP runtime); the status is the same from every entry point"""
+    first, second = ("import torch", "") if order == "torch_first" else ("", "import torch")
+    out, _ = _queue_probe(_QUEUE_CODE.format(first=first, second=second), {})
+    assert out == [str(N.QUEUES_SET_BY_LIBRARY), "12", "12", str(N.QUEUES_SET_BY_LIBRARY), str(N.QUEUES_SET_BY_LIBRARY), "12"]
+
+
+def test_hw_queues_caller_setting_wins_and_late_start_is_reported():
+    out, _ = _queue_probe(_QUEUE_CODE.format(first="", second=""), {"GPU_MAX_HW_QUEUES": "4"})
+    assert out == [str(N.QUEUES_CALLER), "4", "4", str(N.QUEUES_CALLER), str(N.QUEUES_CALLER), "4"]
+    # the runtime already running (a C-ABI consumer whose host initialised HIP first): reported, warned about, nothing set
+    out, err = _queue_probe(_QUEUE_CODE.format(first="", second=""), {"ZKMI_TEST_RUNTIME_STARTED": "1"})
+    assert out == [str(N.QUEUES_TOO_LATE), "0", "-", str(N.QUEUES_TOO_LATE), str(N.QUEUES_TOO_LATE), "0"]
+    assert "GPU_MAX_HW_QUEUES" in err and "RuntimeWarning" in err
+
+
 @pytest.mark.parametrize("name,cid", CURVES)
 @pytest.mark.parametrize("grp", [1, 2])
 def test_point_arithmetic_and_codec(lib, name, cid, grp):

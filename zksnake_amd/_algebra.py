@@ -57,6 +57,7 @@ class PointArray:
         self.group = group
         self.limbs = np.ascontiguousarray(limbs, dtype=np.uint64).reshape(-1, N.point_limbs(curve_id, group))
         self._plans = {}
+        self._plan_layout = {}    # precompute flag -> (window_bits, window_range) the plans of that mode were created with
         self.window_range = None  # (first, count): plans cover only these windows (a rank of a window-sharded prover)
 
     def __len__(self):
@@ -113,6 +114,17 @@ class PointArray:
         which are reused by every proof.  high_priority puts the plan's own stream at the top priority level;
         window_bits 0 = the library's choice for len(self) points."""
         key = (slot, bool(precompute))
+        # clones share the first plan's bases, so all plans of a mode have one window layout: a call that asks for another
+        # width, or comes after window_range changed, drops them and builds anew instead of silently handing back a plan
+        # with the old layout (round-2 advisor finding).  high_priority only picks the stream of a NEW plan.
+        layout = (int(window_bits), self.window_range)
+        have = self._plan_layout.get(bool(precompute))
+        if have is not None and (have[1] != layout[1] or (layout[0] and have[0] != layout[0])):
+            for k in [k for k in self._plans if k[1] == bool(precompute)]:
+                N.load().zk_msm_plan_destroy(self._plans.pop(k))
+            have = None
+        if have is None:
+            self._plan_layout[bool(precompute)] = layout
         if key not in self._plans:
             lib = N.ensure_gpu()
             h = N._u64(0)
@@ -136,6 +148,7 @@ class PointArray:
         for h in self._plans.values():
             N.load().zk_msm_plan_destroy(h)
         self._plans = {}
+        self._plan_layout = {}
 
     def __del__(self):
         try:

@@ -43,6 +43,9 @@ _u64 = ctypes.c_uint64
 # every symbol include/zkmi.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "zk_init": (_i, [_i]),
+    "zk_init_ex": (_i, [_i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "zk_hw_queues_prepare": (_i, [ctypes.POINTER(_i)]),
+    "zk_debug_spin_dev": (_i, [_vp, _u64]),
     "zk_shutdown": (_i, []),
     "zk_device_count": (_i, []),
     "zk_last_error": (ctypes.c_char_p, []),
@@ -54,6 +57,7 @@ SIGNATURES = {
     "zk_host_free": (_i, [_vp]),
     "zk_dev_download": (_i, [_vp, _vp, _u64]),
     "zk_dev_memset": (_i, [_vp, _i, _u64]),
+    "zk_dev_memset_async": (_i, [_vp, _i, _u64, _vp]),
     "zk_dev_synchronize": (_i, []),
     "zk_stream_create": (_i, [_i, ctypes.POINTER(_vp)]),
     "zk_stream_destroy": (_i, [_vp]),
@@ -132,11 +136,8 @@ _lib = None
 _lock = threading.Lock()
 _initialised = False
 
-# A proof keeps seven HIP streams busy (five MSM plans, the QAP chain, the default stream).  The runtime multiplexes streams
-# onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and work of two streams that share a queue runs one after the other:
-# with the default the witness-only MSM and the QAP chain ended up serialised (kernel trace, round 2).  The variable is read
-# when the HIP runtime starts, so it has to be in place before anything touches the GPU; an explicit setting wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+QUEUES_SET_BY_LIBRARY, QUEUES_CALLER, QUEUES_TOO_LATE = 0, 1, 2
+queue_status = None   # set by load(): what zk_hw_queues_prepare decided for this process (include/zkmi.h)
 
 
 def load():
@@ -155,6 +156,16 @@ def load():
                 fn.restype = res
                 fn.argtypes = args
             _lib = lib
+            # hardware queues: the library sets GPU_MAX_HW_QUEUES itself, before its first HIP call, unless the caller chose
+            # a value or the HIP runtime is already running (include/zkmi.h "Hardware queues"); done at load time so that it
+            # also precedes a later `torch.cuda` call of the host program.  No HIP call happens here.
+            global queue_status
+            queue_status = lib.zk_hw_queues_prepare(None)
+            if queue_status == QUEUES_TOO_LATE:
+                import warnings
+                warnings.warn("the HIP runtime was started before libzkmi could set GPU_MAX_HW_QUEUES: the streams of a proof "
+                              "may share hardware queues (slower, not wrong); import zksnake_amd before touching the GPU "
+                              "or export GPU_MAX_HW_QUEUES=12", RuntimeWarning, stacklevel=2)
     return _lib
 
 
@@ -224,6 +235,10 @@ def ints_to_limbs(vals, words=4, modulus=None, out=None):
     `out`: a C-contiguous (n, words) uint64 array to fill (a reused / page-locked staging buffer)."""
     if out is not None:
         assert out.dtype == np.uint64 and out.flags.c_contiguous and out.shape == (len(vals), words)
+    if modulus is not None:
+        modulus = operator.index(modulus)   # an exact int for both paths (numpy integers welcome, floats are a TypeError)
+        if modulus <= 0:
+            raise ValueError("modulus must be a positive integer")
     if _pyints is not None:
         if not isinstance(vals, (list, tuple)):
             vals = list(vals)

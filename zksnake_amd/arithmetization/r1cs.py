@@ -4,11 +4,58 @@ attributes A, B, C (SparseArray), n_public, p; `is_sat`; `from_file` for circom 
 
 The reference builds A, B, C by compiling its symbolic ConstraintSystem (Rust, O(n^2), out of scope here);
 this class is filled directly from matrices (`from_matrices`), from triplet lists, or from a circom file
-whose matrices are kept verbatim in circom wire order (proofs do not depend on the wire order).
+whose matrices are kept verbatim in circom wire order (proofs do not depend on the wire order).  File circuits get a
+`constraint_system` facade with the reference's `unsafe_assign` / `solve` (hint callbacks for wires that propagation alone
+cannot determine: examples/example_bitify_circom.py).
 """
 
 from ..array import SparseArray
 from ..ecc import EllipticCurve
+
+
+class Var:
+    """A named circuit variable: the one role of the reference's `Var` (src/arithmetization/symbolic.rs `Field` with
+    `Gate::Input(name)`) that file circuits need -- naming the target of `unsafe_assign`.  Building expressions with it is
+    the reference's symbolic front end, which is outside the accelerated path."""
+
+    __slots__ = ("name",)
+
+    def __init__(self, name: str):
+        if not isinstance(name, str):
+            raise TypeError("Invalid assignment expression")
+        self.name = name
+
+    def __repr__(self):
+        return f"Var({self.name!r})"
+
+
+class FileConstraintSystem:
+    """`r1cs.constraint_system` of a circuit loaded with `R1CS.from_file`: the two calls the reference's examples make on it
+    (examples/example_bitify_circom.py:11-24) -- `unsafe_assign(Var(name), func, args)` and `solve(inputs)` -- backed by the
+    matrices of the file instead of the reference's symbolic ConstraintSystem."""
+
+    def __init__(self, r1cs):
+        self._r1cs = r1cs
+        self.hints = []   # (target wire, callable, argument names) in registration order
+
+    def unsafe_assign(self, target, func, args):
+        """Non-deterministic assignment (symbolic.rs:634-650): once every variable named in `args` is known, `target`
+        takes `func(**{name: value})`, which must be an int.  `target` must be a plain variable."""
+        if not isinstance(target, Var):
+            raise TypeError("Invalid assignment expression")
+        r = self._r1cs
+        try:
+            wire = r.wire_names.index(target.name, 1)
+        except ValueError:
+            raise KeyError(f"unknown variable {target.name}") from None
+        args = tuple(args)
+        for a in args:
+            if a not in r._wire_of:
+                raise KeyError(f"Argument not exist: {a}")
+        self.hints.append((wire, func, args))
+
+    def solve(self, inputs: dict) -> dict:
+        return self._r1cs.solve(inputs)
 
 
 class R1CS:
@@ -21,6 +68,7 @@ class R1CS:
         self.n_public = (len(cs.public_vars) + 1) if cs is not None else 1
         self.p = EllipticCurve(curve).order
         self.wire_names = None   # from_file: wire index -> variable name (.sym labels, or out1/pub1/priv1/v1 ...)
+        self._wire_of = {}       # from_file: variable name -> wire index
         self.input_wires = ()    # from_file: wires of the declared public and private inputs
 
     # ---- construction -------------------------------------------------------------------------
@@ -50,10 +98,10 @@ class R1CS:
     def compile(self):
         """compile the attached constraint system (must expose the reference's compile_to_r1cs() /
         num_constraints() / num_witness() protocol, arithmetization/r1cs.py:21-40)."""
-        if self.constraint_system is None:
+        if self.constraint_system is None or isinstance(self.constraint_system, FileConstraintSystem):
             if self.A is None:
                 raise ValueError("no constraint system attached")
-            return
+            return   # matrices read from a file are used as they are
         cs = self.constraint_system
         rows, cols = cs.num_constraints(), cs.num_witness() + 1
         self.A = SparseArray([[]], rows, cols, self.p)
@@ -68,7 +116,7 @@ class R1CS:
         """{variable name: value} for every wire, from the declared inputs (reference r1cs.py:42-55).  Circuits loaded
         with `from_file` are solved by constraint propagation over the matrices (`solve_wires`); as in the reference
         only the declared inputs are read (symbolic.rs:654-663) and a missing one is an error."""
-        if self.constraint_system is not None:
+        if self.constraint_system is not None and not isinstance(self.constraint_system, FileConstraintSystem):
             return self.constraint_system.solve(inputs)
         if self.wire_names is None:
             raise NotImplementedError("no symbolic constraint system attached; supply the witness directly")
@@ -78,11 +126,12 @@ class R1CS:
             if name not in inputs:
                 raise ValueError(f"missing value for input variable {name}")
             known[wire] = inputs[name]
-        w = self.solve_wires(known)
+        hints = self.constraint_system.hints if isinstance(self.constraint_system, FileConstraintSystem) else ()
+        w = self.solve_wires(known, hints)
         return {self.wire_names[i]: w[i] for i in range(1, len(w))}
 
     def generate_witness(self, solve_result: dict):
-        if self.constraint_system is None:
+        if self.constraint_system is None or isinstance(self.constraint_system, FileConstraintSystem):
             if self.wire_names is None:
                 raise NotImplementedError("no symbolic constraint system attached; supply the witness directly")
             # circom wire order: [1, public outputs, public inputs, private inputs, intermediates]
@@ -98,11 +147,13 @@ class R1CS:
                 w.append(v % self.p)
         return w[: self.n_public], w[self.n_public:]
 
-    def solve_wires(self, known: dict) -> list:
+    def solve_wires(self, known: dict, hints=()) -> list:
         """Witness by constraint propagation for matrix-only systems (circom files): starting from the wires in
         `known` ({wire index: value}; wire 0 = 1 is implied), repeatedly take a constraint <A,w>*<B,w> = <C,w> in
         which exactly one wire is unknown and appears linearly, and solve for it.  This is the job the reference's
-        symbolic solver does for file circuits (src/arithmetization/symbolic.rs:652-806, one-unknown isolation)."""
+        symbolic solver does for file circuits (src/arithmetization/symbolic.rs:652-806, one-unknown isolation).
+        `hints`: (target wire, callable, argument names) rows of `unsafe_assign`; a hint fires as soon as all its
+        arguments are known (symbolic.rs:748-782) and its result must be an int ("Non deterministic result must be Integer")."""
         assert self.A is not None, "R1CS is not compiled"
         p = self.p
         n_col = self.A.n_col
@@ -124,10 +175,27 @@ class R1CS:
                     acc = (acc + v * w[c]) % p
             return acc, unk
 
-        pending = list(rows.values())
+        def fire_hints(todo):
+            fired, rest = False, []
+            for wire, func, args in todo:
+                vals = [w[self._wire_of[a]] for a in args]
+                if any(v is None for v in vals):
+                    rest.append((wire, func, args))
+                    continue
+                out = func(**dict(zip(args, vals)))
+                if isinstance(out, bool) or not isinstance(out, int):
+                    raise TypeError("Non deterministic result must be Integer")
+                if out < 0:
+                    raise OverflowError("can't convert negative int to unsigned")   # the reference parses the result as BigUint
+                w[wire] = out % p
+                fired = True
+            return fired, rest
+
+        hints_left = list(hints)
+        pending = [rows[i] for i in sorted(rows)]
         progress = True
-        while pending and progress:
-            progress = False
+        while (pending or hints_left) and progress:
+            progress, hints_left = fire_hints(hints_left)
             rest = []
             for row in pending:
                 (sa, ua), (sb, ub), (sc, uc) = split(row["a"]), split(row["b"]), split(row["c"])
@@ -155,6 +223,13 @@ class R1CS:
             pending = rest
         if any(x is None for x in w):
             raise ValueError("constraint propagation could not determine every wire from the given inputs")
+        if hints:
+            # a hint is taken on trust when it fires; the reference asserts every constraint once all its variables are
+            # known (symbolic.rs:684-696), so a wrong hint must not pass silently here either
+            for i, row in sorted(rows.items()):
+                (sa, _), (sb, _), (sc, _) = split(row["a"]), split(row["b"]), split(row["c"])
+                if sa * sb % p != sc:
+                    raise AssertionError(f"constraint {i} is not satisfied by the hinted assignment")
         return w
 
     def is_sat(self, public_witness: list, private_witness: list):
@@ -248,6 +323,8 @@ class R1CS:
             raise ValueError(f"the symbol file names no variable for wires {missing[:8]}{'...' if len(missing) > 8 else ''}")
         names[0] = "0"
         self.wire_names = names
+        self._wire_of = {name: i for i, name in enumerate(names) if i > 0}
+        self.constraint_system = FileConstraintSystem(self)
         self.header = dict(n_wires=n_wires, n_pub_out=n_pub_out, n_pub_in=n_pub_in, n_priv_in=n_priv_in,
                            m_constraints=m_constraints, prime=prime)
         return self

@@ -7,6 +7,9 @@
 // g1()/g2(), and for get_evaluation_point / evaluate_lagrange_coefficients
 // (src/bn254/polynomial.rs:518-533,645-652).  The reference runs all of these on the CPU as
 // well: they touch one point (or O(n) scalars at setup time), not the proving hot path.
+#include <dirent.h>
+#include <unistd.h>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -328,6 +331,66 @@ static int scale_add_impl(uint64_t n, uint64_t* acc, const uint64_t* x, const ui
 
 static int g_device = -1;
 
+// ---- hardware queues ---------------------------------------------------------------------------------------------
+// A proof keeps seven HIP streams busy (five MSM plans, the QAP chain, the default stream).  The runtime multiplexes streams
+// onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and work of two streams that share a queue runs one after the
+// other: with the default the witness-only MSM and the QAP chain of Groth16.prove ended up serialised (kernel trace, round
+// 2: ~ +1 ms per proof).  The variable is read when the HIP runtime STARTS (first HIP call of the process), so the library
+// puts it in place before its own first HIP call -- unless the caller chose a value, or somebody else (torch, another
+// library) started the runtime earlier, which this reports instead of hiding.
+constexpr int ZK_WANT_HW_QUEUES = 12;
+static std::mutex g_queue_mu;
+static int g_queue_status = -1, g_queue_count = 0;
+
+// The ROCm runtime opens /dev/kfd when it starts: an open descriptor on it means the environment was already read.
+static bool hip_runtime_started() {
+    if (const char* t = getenv("ZKMI_TEST_RUNTIME_STARTED")) return atoi(t) != 0;   // CPU tests: there is no /dev/kfd to open
+    DIR* d = opendir("/proc/self/fd");
+    if (!d) return false;
+    bool found = false;
+    char path[64], target[256];
+    while (struct dirent* e = readdir(d)) {
+        if (e->d_name[0] == '.') continue;
+        snprintf(path, sizeof(path), "/proc/self/fd/%s", e->d_name);
+        const ssize_t k = readlink(path, target, sizeof(target) - 1);
+        if (k <= 0) continue;
+        target[k] = 0;
+        if (strcmp(target, "/dev/kfd") == 0) { found = true; break; }
+    }
+    closedir(d);
+    return found;
+}
+
+static int hw_queues_prepare(int* queues) {
+    std::lock_guard<std::mutex> lock(g_queue_mu);
+    if (g_queue_status < 0) {
+        const bool started = hip_runtime_started();
+        const char* env = getenv("GPU_MAX_HW_QUEUES");
+        if (env && *env) {
+            g_queue_count = atoi(env);
+            // set before the runtime started, or by whoever started it: either way it is what the runtime uses
+            g_queue_status = ZK_QUEUES_CALLER;
+        } else if (!started) {
+            char v[16];
+            snprintf(v, sizeof(v), "%d", ZK_WANT_HW_QUEUES);
+            setenv("GPU_MAX_HW_QUEUES", v, 0);
+            g_queue_count = ZK_WANT_HW_QUEUES;
+            g_queue_status = ZK_QUEUES_SET_BY_LIBRARY;
+        } else {
+            g_queue_count = 0;   // the runtime's default (4)
+            g_queue_status = ZK_QUEUES_TOO_LATE;
+        }
+    }
+    if (queues) *queues = g_queue_count;
+    return g_queue_status;
+}
+
+// busy-wait kernel of the concurrency probe (tests): holds one wave for `ticks` of the constant 100 MHz counter
+__global__ void spin_kernel(uint64_t ticks) {
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+}
+
 }  // namespace zkmi
 
 using namespace zkmi;
@@ -340,12 +403,27 @@ int zk_device_count(void) {
     return n;
 }
 
+int zk_hw_queues_prepare(int* queues) { return hw_queues_prepare(queues); }
+
 int zk_init(int device) {
+    (void)hw_queues_prepare(nullptr);   // before the first HIP call below
     int n = zk_device_count();
     if (n <= 0) return fail(ZK_ERR_HIP, "no HIP device visible: libzkmi has no CPU fallback");
     if (device < 0 || device >= n) return fail(ZK_ERR_ARG, "device index out of range");
     ZK_HIP(hipSetDevice(device));
     g_device = device;
+    return ZK_OK;
+}
+
+int zk_init_ex(int device, int* queue_status, int* queues) {
+    const int st = hw_queues_prepare(queues);
+    if (queue_status) *queue_status = st;
+    return zk_init(device);
+}
+
+int zk_debug_spin_dev(void* stream, uint64_t microseconds) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, microseconds * 100ull);
+    ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
 
@@ -376,6 +454,10 @@ int zk_dev_download(void* h_dst, const void* d_src, uint64_t bytes) {
 }
 int zk_dev_memset(void* d_dst, int value, uint64_t bytes) {
     if (bytes) ZK_HIP(hipMemset(d_dst, value, bytes));
+    return ZK_OK;
+}
+int zk_dev_memset_async(void* d_dst, int value, uint64_t bytes, void* stream) {
+    if (bytes) ZK_HIP(hipMemsetAsync(d_dst, value, bytes, (hipStream_t)stream));
     return ZK_OK;
 }
 int zk_host_alloc(uint64_t bytes, void** h_ptr) {

@@ -1384,7 +1384,7 @@ struct MsmPlan : MsmPlanBase {
         if (c < 2 || c > MAX_C) return fail(ZK_ERR_ARG, "window bits must be in [2, 20]");
         if (c > 16 && !pre) return fail(ZK_ERR_ARG, "windows wider than 16 bits need a fixed-base plan (ZK_MSM_PRECOMPUTE)");
         wide = c > 16;
-        nwin = glv ? (GLV_BITS + c - 1) / c : (FrP::BITS + 1 + c - 1) / c;
+        nwin = glv ? glv_window_count(c) : window_count(FrP::BITS + 1, c);
         if (win_count <= 0) { win_first = 0; win_count = nwin; }
         if (win_first < 0 || win_first + win_count > nwin) return fail(ZK_ERR_ARG, "window range out of bounds");
         pw_first = win_first;

@@ -29,7 +29,7 @@ struct SortExport {
 };
 
 // ---- window layout of a plan (shared by MsmPlan::init and zk_msm_window_layout) -----------------------------------
-constexpr int GLV_BITS = 128;                    // k + bias must fit nwin * c >= GLV_BITS bits (|k1|, |k2| < 2^127 - 2^112)
+constexpr int GLV_BITS = 128;                    // the halves are signed 128-bit values, |k1|, |k2| <= 0.68 * 2^127 (BLS12-381; BN254: < 2^126)
 constexpr uint64_t GLV_MAX_POINTS = 1ull << 22;  // 2n entries per window must leave the two-level sort its 8 fine bits
 constexpr int MSM_WIDE_C_DEFAULT = 20;           // fixed-base plans over all windows: measured at 2^20 BN254 G1, see DESIGN.md
 
@@ -38,6 +38,18 @@ inline int msm_log2(uint64_t v) {
     while (v >>= 1) ++l;
     return l;
 }
+
+// Windows of a plan.  The digits kernels add the bias b = sum_w 2^(c-1) 2^(cw) to the scalar (or to a signed half k of it)
+// and cut the sum into nwin plain c-bit fields, so they need 0 <= k + b < 2^(nwin c): b >= |k| always holds, and the room
+// above b is 2^(nwin c) (2^(c-1) - 1) / (2^c - 1), at least (3/7) 2^(nwin c) for c >= 3: with nwin = ceil(bits / c) that
+// covers r - 1 over bits = BITS + 1 for both scalar fields and 0.68 * 2^127 over bits = 128 for the halves (checked for
+// every c in 3 .. 20).  For c = 2 the factor is only 1/3 -- 0.667 * 2^127 against BLS12-381 halves of up to 0.673 * 2^127,
+// 0.333 * 2^256 against r = 0.453 * 2^256 -- the top digit overflowed and was masked off (round-2 advisor finding), so
+// two-bit windows take one more window.
+inline int window_count(int bits, int c) {
+    return (bits + c - 1) / c + (c == 2 ? 1 : 0);
+}
+inline int glv_window_count(int c) { return window_count(GLV_BITS, c); }
 
 inline int pick_window_bits(uint64_t entries) {
     // bucket sets must fit the LDS histogram (c <= 16) and stay well filled
@@ -83,7 +95,7 @@ inline MsmLayout msm_layout(int scalar_bits, bool has_glv, uint64_t n_points, in
         }
     }
     L.c = c;
-    L.nwin = c > 0 ? (L.glv ? (GLV_BITS + c - 1) / c : (scalar_bits + 1 + c - 1) / c) : 0;
+    L.nwin = c > 0 ? (L.glv ? glv_window_count(c) : window_count(scalar_bits + 1, c)) : 0;
     return L;
 }
 

@@ -118,12 +118,23 @@ static PyObject* ints_to_limbs(PyObject* self, PyObject* args) {
     uint64_t mod_words[16];
     int have_mod = modulus != Py_None;
     PyObject* result = NULL;
+    PyObject* mod_obj = NULL;   /* the modulus as an exact int (new reference) */
     unsigned char* slow = NULL;
     if ((size_t)out.len < (size_t)n * nbytes || nbytes > sizeof(mod_bytes) || words < 1) {
         PyErr_SetString(PyExc_ValueError, "output buffer too small");
         goto done;
     }
-    if (have_mod && _PyLong_AsByteArray((PyLongObject*)modulus, mod_bytes, nbytes, 1, 0) < 0) goto done;
+    if (have_mod) {
+        /* any integer-like modulus (int, numpy integer) through __index__; a non-integer raises TypeError as the pure-Python
+         * path does, and a modulus below 1 is rejected instead of being read as unsigned bytes */
+        mod_obj = PyNumber_Index(modulus);
+        if (!mod_obj) goto done;
+        if (_PyLong_Sign(mod_obj) <= 0) {
+            PyErr_SetString(PyExc_ValueError, "modulus must be a positive integer");
+            goto done;
+        }
+        if (_PyLong_AsByteArray((PyLongObject*)mod_obj, mod_bytes, nbytes, 1, 0) < 0) goto done;
+    }
     slow = (unsigned char*)malloc(n > 0 ? (size_t)n : 1);
     if (!slow) { PyErr_NoMemory(); goto done; }
     memcpy(mod_words, mod_bytes, have_mod ? nbytes : 0);
@@ -159,7 +170,7 @@ static PyObject* ints_to_limbs(PyObject* self, PyObject* args) {
             need_reduce = cmp >= 0;
         }
         if (need_reduce) {
-            PyObject* r = PyNumber_Remainder(v, modulus);
+            PyObject* r = PyNumber_Remainder(v, mod_obj);
             if (!r) { Py_DECREF(v); goto done; }
             int rc = _PyLong_AsByteArray((PyLongObject*)r, p, nbytes, 1, 0);
             Py_DECREF(r);
@@ -171,6 +182,7 @@ static PyObject* ints_to_limbs(PyObject* self, PyObject* args) {
     result = Py_None;
 done:
     free(slow);
+    Py_XDECREF(mod_obj);
     Py_DECREF(fast);
     PyBuffer_Release(&out);
     return result;

@@ -52,6 +52,7 @@ class Groth16:
         self._blinding = None   # tests may pin (r, s)
         self.precompute_keys = True  # proving-key MSM plans use the fixed-base table (ZK_MSM_PRECOMPUTE)
         self.last_timings = {}
+        self._live = []         # MSM plan handles with a run in flight (prove() cancels them when it fails half way)
         self._shard = None      # (rank, world, torch device or None) once shard_over_ranks() was called
 
     # ------------------------------------------------------------------------------------------
@@ -219,9 +220,11 @@ class Groth16:
         if share_sort_of is not None and count == len(arr) and not os.environ.get("ZKMI_NO_SHARED_SORT"):
             # <tau_1, v> is already in flight with the same scalars: B2 = <tau_2, v> reuses its digits and sorted entries
             if lib.zk_msm_plan_enqueue_shared(handle, share_sort_of, N.STREAM_PLAN) == N.ZK_OK:
+                self._live.append(handle)
                 return arr, handle
         enqueue = lib.zk_msm_plan_enqueue_sort if sort_only else lib.zk_msm_plan_enqueue
         N.check(enqueue(handle, count, d_scalars, 1, first, cnt, N.STREAM_PLAN))
+        self._live.append(handle)
         return arr, handle
 
     @staticmethod
@@ -237,6 +240,8 @@ class Groth16:
         out = np.zeros(N.point_limbs(self.E.curve.curve_id, group), dtype=np.uint64)
         if handle is not None:
             N.check(lib.zk_msm_plan_finish(handle, N.u64p(out)))
+            if handle in self._live:
+                self._live.remove(handle)
         return out
 
     def _exchange(self, parts):
@@ -295,16 +300,26 @@ class Groth16:
             pk.tau_1, early["v1"] = self._enqueue_msm(pk.tau_1, 1, d_v.ptr, min(n_rows, len(pk.tau_1)), slot=1, sort_only=True, wait_event=event)
             pk.tau_1, early["u"] = self._enqueue_msm(pk.tau_1, 1, d_u.ptr, min(n_rows, len(pk.tau_1)), slot=0, sort_only=True, wait_event=event)
 
+        # A plan accepts one run at a time: whatever goes wrong between the first enqueue and the last finish (a witness that
+        # fails the divisibility check, an allocation failure, a HIP error, KeyboardInterrupt), the runs still in flight are
+        # cancelled before the exception leaves, or every later prove() on this key would fail with "already has a run in flight"
+        self._live = []
         try:
-            res = self.qap.evaluate_witness_device(witness, after_upload=start_witness_msm, after_uv=start_uv_sorts if ordered else None)
-        except ValueError as exc:
-            if early.get("k") is not None:  # drain the runs in flight: a plan accepts one at a time
-                self._finish_msm(early["k"], 1)
-            for key in ("v1", "u"):
-                if early.get(key) is not None:
-                    N.check(N.load().zk_msm_plan_cancel(early[key]))
-            raise ValueError("Failed to evaluate with the given witness") from exc
+            try:
+                res = self.qap.evaluate_witness_device(witness, after_upload=start_witness_msm, after_uv=start_uv_sorts if ordered else None)
+            except ValueError as exc:
+                raise ValueError("Failed to evaluate with the given witness") from exc
+            return self._prove_msms(pk, res, early, ordered, r, s, q, t_start)
+        except BaseException:
+            lib = N.load()
+            for handle in self._live:
+                lib.zk_msm_plan_cancel(handle)   # status ignored: the original exception is the one to report
+            raise
+        finally:
+            self._live = []
 
+    def _prove_msms(self, pk, res, early, ordered, r, s, q, t_start):
+        import time
         t_qap = time.perf_counter()
         n = res.n
         # The four MSMs over u, v, h run on their plans' own streams.  An accumulate kernel fills every wave slot of the

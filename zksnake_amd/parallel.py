@@ -41,13 +41,12 @@ def all_gather_limbs(mine, device=None):
     mine = torch.from_numpy(np.ascontiguousarray(mine, dtype=np.uint64).view(np.int64))
     if device is not None:
         mine = mine.to(device)
-    gathered = torch.zeros((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
-    try:
-        dist.all_gather_into_tensor(gathered, mine)  # one flat collective (RCCL all-gather)
-    except (RuntimeError, NotImplementedError):
-        bucket = list(gathered.unbind(0))
-        dist.all_gather(bucket, mine)
-        gathered = torch.stack(bucket)
+    # one flat collective (RCCL all-gather over xGMI; gloo on the CPU).  The output is the concatenation of the ranks'
+    # vectors -- the form both backends accept -- and there is no fallback path: a failing collective surfaces as it is
+    # (round-2 verdict: a retry with all_gather would have masked a genuine RCCL error on the first multi-GPU run)
+    flat = torch.zeros(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(flat, mine.reshape(-1))
+    gathered = flat.view((world,) + tuple(mine.shape))
     return gathered.cpu().numpy().view(np.uint64)
 
 

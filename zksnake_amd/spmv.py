@@ -54,7 +54,7 @@ class DeviceCsr:
         """d_out[row] = sum_k vals[k] * d_w[cols[k]] (device pointers); rows without entries give 0"""
         lib = N.load()
         if self.cols is None:
-            N.check(lib.zk_dev_memset(d_out, 0, self.n_rows * 32))
+            N.check(lib.zk_dev_memset_async(d_out, 0, self.n_rows * 32, stream))   # ordered with the kernels that read d_out on `stream`
             return
         N.check(lib.zk_spmv_dev(self.cid, self.n_rows, self.row_ptr.ptr, self.cols.ptr, self.vals.ptr, d_w, d_out,
                                 LONG_ROW if self.n_long else 0, stream))
