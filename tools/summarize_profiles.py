@@ -20,6 +20,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools.fingerprint import source_fingerprint  # noqa: E402
 
 
 def per_kernel(path, counter):
@@ -67,11 +69,52 @@ def main():
             if key:
                 with open(os.path.join(prof, "msm_traffic.json"), "w") as f:
                     json.dump({
-                        "accumulate_hbm_bytes_per_launch": summary[key]["hbm_bytes_per_launch_corrected"],
+                        "hbm_bytes": summary[key]["hbm_bytes_per_launch_corrected"],
+                        "kernel": key,
+                        "source_fingerprint": source_fingerprint("msm"),
                         "source": f"profiles/{tag}_bench_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on "
                                   "`bench.py --steps 3`, (2*FETCH_SIZE + WRITE_SIZE) KiB per launch (gfx950 half-count correction)",
                     }, f, indent=1)
+        if w == "prove":
+            # one steady-state proof = every kernel of the prove path once per proof; setup-only kernels are left out.
+            # proofs in the run = launches of the G2 accumulate kernel (one per proof)
+            proofs = next((v["launches_sampled"] for k, v in summary.items() if k.startswith("zkmi::accumulate_kernel<zkmi::Bn254G2>")), 0)
+            setup_only = ("fixed_mul_kernel", "fixed_table_kernel", "normalize_kernel", "dbl_rows_kernel", "varbase_mul_kernel", "powers_kernel",
+                          "twiddle_kernel", "bases_to_mont_kernel", "vec_axpby", "points_encode", "points_decode")
+            if proofs:
+                total = sum(v["hbm_bytes_per_launch_corrected"] * v["launches_sampled"] for k, v in summary.items()
+                            if not any(s in k for s in setup_only))
+                with open(os.path.join(prof, "prove_traffic.json"), "w") as f:
+                    json.dump({
+                        "hbm_bytes": int(total / proofs),
+                        "proofs_in_run": proofs,
+                        "source_fingerprint": source_fingerprint("prove"),
+                        "source": f"profiles/{tag}_prove_pmc_summary.json: FETCH_SIZE / WRITE_SIZE passes over tools/prove_bench.py --log-n 20, sum over the "
+                                  "prove-path kernels of (2*FETCH_SIZE + WRITE_SIZE) KiB x launches, divided by the proofs in the run (setup-only "
+                                  "kernels left out; the matrices' SpMV of the first proof's upload is included once per proof)",
+                    }, f, indent=1)
         print(w, "summarised")
+    for w in ("bench", "ntt"):
+        sq_csv = first(os.path.join(out_root, f"{prefix}_{w}_sq", "**", "*_counter_collection.csv"))
+        if not sq_csv:
+            continue
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        with open(sq_csv) as f:
+            for row in csv.DictReader(f):
+                acc[row["Kernel_Name"].split("(")[0].replace("void ", "")][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        sq = {}
+        for k, ctrs in sorted(acc.items()):
+            sq[k] = {c: round(sum(v) / len(v), 1) for c, v in sorted(ctrs.items())}
+            sq[k]["launches"] = max(len(v) for v in ctrs.values())
+            wc, act, wi = sq[k].get("SQ_WAVE_CYCLES"), sq[k].get("SQ_ACTIVE_INST_VALU"), sq[k].get("SQ_WAIT_INST_ANY")
+            if wc and sq[k].get("SQ_WAVES"):
+                sq[k]["valu_instructions_per_wave"] = round(sq[k].get("SQ_INSTS_VALU", 0.0) / sq[k]["SQ_WAVES"], 1)
+                # SQ_WAVE_CYCLES, SQ_WAIT_* and SQ_ACTIVE_* count in units of 4 cycles per wave: shares of a wave's residency
+                sq[k]["share_of_wave_cycles"] = {"valu_executing": round((act or 0.0) / wc, 3), "waiting_to_issue": round((wi or 0.0) / wc, 3)}
+        with open(os.path.join(prof, f"{tag}_{w}_pmc_sq.json"), "w") as f:
+            json.dump({"command": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU "
+                                  "SQ_BUSY_CYCLES SQ_WAVES --kernel-trace (tools/collect_profiles.sh runsq)", "kernels": sq}, f, indent=1)
+        print(w, "sq counters summarised")
     print("profiles updated for", tag)
 
 

@@ -270,3 +270,9 @@ def limbs_to_ints(arr):
     raw = arr.tobytes()
     step = 8 * words
     return [int.from_bytes(raw[i:i + step], "little") for i in range(0, len(raw), step)]
+
+
+# The library is loaded when this module is imported (ImportError when it has not been built: there is no CPU fallback),
+# so that zk_hw_queues_prepare runs before a host program that imports zksnake_amd first and only then touches the GPU
+# through torch starts the HIP runtime.
+load()
