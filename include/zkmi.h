@@ -79,6 +79,9 @@ int zk_dev_alloc(uint64_t bytes, void** d_ptr);
 int zk_dev_free(void* d_ptr);
 int zk_dev_upload(void* d_dst, const void* h_src, uint64_t bytes);
 int zk_dev_download(void* h_dst, const void* d_src, uint64_t bytes);
+/* upload ordered on `stream` and asynchronous to the host when h_src is page-locked (zk_host_alloc): lets a host that
+ * marshals a long witness chunk by chunk ship chunk k while it converts chunk k + 1 */
+int zk_dev_upload_async(void* d_dst, const void* h_src, uint64_t bytes, void* stream);
 int zk_dev_memset(void* d_dst, int value, uint64_t bytes);
 /* the same, ordered on `stream` (NULL = default stream): zk_dev_memset runs on the legacy default stream, which does not
  * synchronise with the non-blocking streams of zk_stream_create */

@@ -34,7 +34,7 @@ print(N.queue_status, round((time.perf_counter() - t0) * 1e3, 1))
 
 
 def _run(prelude, env_extra):
-    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "ZKMI_HW_QUEUES_SET_BY_LIBRARY")}
     env.update(env_extra)
     env["PYTHONPATH"] = ROOT
     res = subprocess.run([sys.executable, "-c", _PROBE.format(prelude=prelude)], env=env, capture_output=True, text=True, timeout=600)

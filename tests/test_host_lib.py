@@ -52,7 +52,7 @@ def _queue_probe(code, env_extra):
     """run `code` in a fresh interpreter (the decision is taken once per process) and return its stdout lines"""
     import subprocess
     import sys
-    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "ZKMI_TEST_RUNTIME_STARTED")}
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "ZKMI_TEST_RUNTIME_STARTED", "ZKMI_HW_QUEUES_SET_BY_LIBRARY")}
     env.update(env_extra)
     env["PYTHONPATH"] = ROOT
     res = subprocess.run([sys.executable, "-W", "always", "-c", code], env=env, capture_output=True, text=True, timeout=300)

@@ -53,6 +53,7 @@ SIGNATURES = {
     "zk_dev_alloc": (_i, [_u64, ctypes.POINTER(_vp)]),
     "zk_dev_free": (_i, [_vp]),
     "zk_dev_upload": (_i, [_vp, _vp, _u64]),
+    "zk_dev_upload_async": (_i, [_vp, _vp, _u64, _vp]),
     "zk_host_alloc": (_i, [_u64, ctypes.POINTER(_vp)]),
     "zk_host_free": (_i, [_vp]),
     "zk_dev_download": (_i, [_vp, _vp, _u64]),
@@ -140,6 +141,37 @@ QUEUES_SET_BY_LIBRARY, QUEUES_CALLER, QUEUES_TOO_LATE = 0, 1, 2
 queue_status = None   # set by load(): what zk_hw_queues_prepare decided for this process (include/zkmi.h)
 
 
+def _prepare_hw_queues_early():
+    """The hardware-queue setting belongs to the C library (zk_hw_queues_prepare, include/zkmi.h), but the library itself is
+    loaded lazily, on first use: loading it at import time would pull in /opt/rocm's libamdhip64 before a later
+    `import torch` loads the copy bundled with torch by path -- two HIP runtimes in one process, and the second one finds no
+    device.  So the import of this module only does what zk_hw_queues_prepare would do at that moment (same rule: the
+    caller's setting wins, nothing is set once the runtime runs) and leaves a marker for the library to report it as its own."""
+    if os.environ.get("GPU_MAX_HW_QUEUES"):
+        return
+    started = os.environ.get("ZKMI_TEST_RUNTIME_STARTED")
+    if started is not None:
+        running = started not in ("", "0")
+    else:
+        running = False
+        try:
+            for fd in os.listdir("/proc/self/fd"):
+                try:
+                    if os.readlink("/proc/self/fd/" + fd) == "/dev/kfd":
+                        running = True
+                        break
+                except OSError:
+                    continue
+        except OSError:
+            pass
+    if not running:
+        os.environ["GPU_MAX_HW_QUEUES"] = "12"
+        os.environ["ZKMI_HW_QUEUES_SET_BY_LIBRARY"] = "1"
+
+
+_prepare_hw_queues_early()
+
+
 def load():
     """dlopen libzkmi.so and attach prototypes; raises if the library has not been built."""
     global _lib
@@ -157,8 +189,7 @@ def load():
                 fn.argtypes = args
             _lib = lib
             # hardware queues: the library sets GPU_MAX_HW_QUEUES itself, before its first HIP call, unless the caller chose
-            # a value or the HIP runtime is already running (include/zkmi.h "Hardware queues"); done at load time so that it
-            # also precedes a later `torch.cuda` call of the host program.  No HIP call happens here.
+            # a value or the HIP runtime is already running (include/zkmi.h "Hardware queues").  No HIP call happens here.
             global queue_status
             queue_status = lib.zk_hw_queues_prepare(None)
             if queue_status == QUEUES_TOO_LATE:
@@ -228,11 +259,16 @@ except ImportError:  # pragma: no cover - e.g. a different interpreter than the 
     _pyints = None
 
 
-def ints_to_limbs(vals, words=4, modulus=None, out=None):
+PIPELINE_CHUNK = 1 << 18   # elements per chunk of a pipelined conversion (8 MiB of limbs: 0.16 ms on the link)
+
+
+def ints_to_limbs(vals, words=4, modulus=None, out=None, chunk_done=None):
     """list of non-negative ints -> (n, words) uint64, little-endian limbs.  Negative ints raise
     OverflowError, as pyo3's BigUint extraction does in the reference; with `modulus` values are
     reduced first, which is what `Fr::from(BigUint)` does (src/bn254/curve.rs:359).
-    `out`: a C-contiguous (n, words) uint64 array to fill (a reused / page-locked staging buffer)."""
+    `out`: a C-contiguous (n, words) uint64 array to fill (a reused / page-locked staging buffer).
+    `chunk_done(begin, end)`: called after rows [begin, end) of `out` are final (long lists are converted in chunks of
+    PIPELINE_CHUNK elements), so that the caller can start moving them while the rest is converted."""
     if out is not None:
         assert out.dtype == np.uint64 and out.flags.c_contiguous and out.shape == (len(vals), words)
     if modulus is not None:
@@ -244,7 +280,16 @@ def ints_to_limbs(vals, words=4, modulus=None, out=None):
             vals = list(vals)
         if out is None:
             out = np.empty((len(vals), words), dtype=np.uint64)
-        _pyints.ints_to_limbs(vals, words, modulus, out)
+        if chunk_done is None or len(vals) < 2 * PIPELINE_CHUNK:
+            _pyints.ints_to_limbs(vals, words, modulus, out)
+            if chunk_done is not None:
+                chunk_done(0, len(vals))
+        else:
+            # chunk by chunk WITHOUT slicing the list: the caller ships rows [b, e) while the next chunk is converted
+            for b in range(0, len(vals), PIPELINE_CHUNK):
+                e = min(len(vals), b + PIPELINE_CHUNK)
+                _pyints.ints_to_limbs(vals, words, modulus, out, b, e)
+                chunk_done(b, e)
         return out
     nbytes = 8 * words
     chunks = []
@@ -257,8 +302,11 @@ def ints_to_limbs(vals, words=4, modulus=None, out=None):
         chunks.append(v.to_bytes(nbytes, "little"))
     arr = np.frombuffer(b"".join(chunks), dtype=np.uint64).reshape(len(vals), words)
     if out is None:
-        return arr.copy()
-    out[:] = arr
+        out = arr.copy()
+    else:
+        out[:] = arr
+    if chunk_done is not None:
+        chunk_done(0, len(vals))
     return out
 
 
@@ -271,8 +319,3 @@ def limbs_to_ints(arr):
     step = 8 * words
     return [int.from_bytes(raw[i:i + step], "little") for i in range(0, len(raw), step)]
 
-
-# The library is loaded when this module is imported (ImportError when it has not been built: there is no CPU fallback),
-# so that zk_hw_queues_prepare runs before a host program that imports zksnake_amd first and only then touches the GPU
-# through torch starts the HIP runtime.
-load()

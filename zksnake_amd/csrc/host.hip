@@ -368,12 +368,16 @@ static int hw_queues_prepare(int* queues) {
         const char* env = getenv("GPU_MAX_HW_QUEUES");
         if (env && *env) {
             g_queue_count = atoi(env);
-            // set before the runtime started, or by whoever started it: either way it is what the runtime uses
-            g_queue_status = ZK_QUEUES_CALLER;
+            // set before the runtime started, or by whoever started it: either way it is what the runtime uses.  The
+            // Python host of this library applies the same rule when it is imported (it loads the library lazily, see
+            // zksnake_amd/_native.py) and says so through ZKMI_HW_QUEUES_SET_BY_LIBRARY.
+            const char* ours = getenv("ZKMI_HW_QUEUES_SET_BY_LIBRARY");
+            g_queue_status = (ours && *ours == '1' && g_queue_count == ZK_WANT_HW_QUEUES) ? ZK_QUEUES_SET_BY_LIBRARY : ZK_QUEUES_CALLER;
         } else if (!started) {
             char v[16];
             snprintf(v, sizeof(v), "%d", ZK_WANT_HW_QUEUES);
             setenv("GPU_MAX_HW_QUEUES", v, 0);
+            setenv("ZKMI_HW_QUEUES_SET_BY_LIBRARY", "1", 1);   // child processes inherit both: they report the same status
             g_queue_count = ZK_WANT_HW_QUEUES;
             g_queue_status = ZK_QUEUES_SET_BY_LIBRARY;
         } else {
@@ -446,6 +450,10 @@ int zk_dev_free(void* d_ptr) {
 }
 int zk_dev_upload(void* d_dst, const void* h_src, uint64_t bytes) {
     if (bytes) ZK_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return ZK_OK;
+}
+int zk_dev_upload_async(void* d_dst, const void* h_src, uint64_t bytes, void* stream) {
+    if (bytes) ZK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     return ZK_OK;
 }
 int zk_dev_download(void* h_dst, const void* d_src, uint64_t bytes) {

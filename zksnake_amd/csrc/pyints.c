@@ -5,8 +5,10 @@
  * do the same for 2^20 and more witness values per call; `int.to_bytes` per element costs ~180 ms at 2^20, one thread of this loop ~45, eight ~8.
  * Pure marshalling: no field arithmetic happens here (values >= the modulus take the Python-level `%`).
  */
+#define _GNU_SOURCE
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
+#include <sched.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -57,13 +59,21 @@ typedef struct {
     unsigned char* dst;
     const uint64_t* mod;   /* NULL = no modulus */
     unsigned char* slow;   /* per element: 1 = leave to the general path */
+    int any_slow;          /* out: some element of [begin, end) was flagged */
 } PackJob;
 
 static void* pack_worker(void* arg) {
     PackJob* job = (PackJob*)arg;
     const size_t nbytes = job->words * 8;
+    int any = 0;
     for (Py_ssize_t i = job->begin; i < job->end; ++i) {
-        if (i + 8 < job->end) __builtin_prefetch(job->items[i + 8]);
+        /* the walk is bound by the latency of the int objects (64 MB of them at 2^20, in allocation order at best): ask for
+         * both cache lines a 254-bit int can straddle, well ahead */
+        if (i + 24 < job->end) {
+            const char* nxt = (const char*)job->items[i + 24];
+            __builtin_prefetch(nxt);
+            __builtin_prefetch(nxt + 56);
+        }
         PyObject* item = job->items[i];
         unsigned char* p = job->dst + (size_t)i * nbytes;
         int ok = PyLong_CheckExact(item) && pack_digits(item, p, job->words) == 0;
@@ -75,40 +85,132 @@ static void* pack_worker(void* arg) {
             ok = cmp < 0;
         }
         job->slow[i] = (unsigned char)!ok;
+        any |= !ok;
+    }
+    job->any_slow = any;
+    return NULL;
+}
+
+#define PACK_MAX_THREADS 32
+#define PACK_PARALLEL_MIN 16384
+
+/* worker threads of one call: the cores this process may run on (its affinity mask, not the machine's core count: a
+ * container or a GPU box share sees 256 cores and owns 16), at most PACK_MAX_THREADS; ZKMI_PACK_THREADS overrides */
+static int pack_threads(void) {
+    static int cached = 0;
+    if (cached) return cached;
+    long t = 0;
+    const char* e = getenv("ZKMI_PACK_THREADS");
+    if (e && *e) t = atol(e);
+    if (t <= 0) {
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) t = CPU_COUNT(&set);
+        else t = sysconf(_SC_NPROCESSORS_ONLN);
+        if (t > 16) t = 16;
+    }
+    if (t < 1) t = 1;
+    if (t > PACK_MAX_THREADS) t = PACK_MAX_THREADS;
+    cached = (int)t;
+    return cached;
+}
+
+/* Persistent worker pool: creating and joining 16 threads costs ~0.4 ms per call, a quarter of the conversion of a 2^20
+ * witness.  The workers sleep on a condition variable between calls; a call hands each of them one PackJob (generation
+ * counter) and waits for the count of finished jobs.  Calls are serialised by the GIL (the caller holds it throughout). */
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t wake, done;
+    pthread_t tids[PACK_MAX_THREADS];
+    PackJob* jobs;          /* jobs[1 .. n_jobs-1] belong to the workers 1 .. n_jobs-1 */
+    int n_workers;          /* threads created (worker ids 1 .. n_workers) */
+    int n_jobs, finished;
+    unsigned long generation;
+    pid_t owner;            /* a forked child starts without the threads: it builds its own pool */
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, NULL, 0, 0, 0, 0, 0};
+
+static void* pool_main(void* arg) {
+    const int id = (int)(intptr_t)arg;
+    unsigned long seen = 0;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (g_pool.generation == seen) pthread_cond_wait(&g_pool.wake, &g_pool.mu);
+        seen = g_pool.generation;
+        if (id < g_pool.n_jobs) {
+            PackJob* job = &g_pool.jobs[id];
+            pthread_mutex_unlock(&g_pool.mu);
+            pack_worker(job);
+            pthread_mutex_lock(&g_pool.mu);
+            if (++g_pool.finished == g_pool.n_jobs - 1) pthread_cond_signal(&g_pool.done);
+        }
     }
     return NULL;
 }
 
-#define PACK_MAX_THREADS 8
-#define PACK_PARALLEL_MIN 16384
-
-static void pack_fast(PyObject** items, Py_ssize_t n, size_t words, unsigned char* dst, const uint64_t* mod, unsigned char* slow) {
-    long cores = sysconf(_SC_NPROCESSORS_ONLN);
-    int threads = n >= PACK_PARALLEL_MIN ? (int)(cores > PACK_MAX_THREADS ? PACK_MAX_THREADS : (cores < 1 ? 1 : cores)) : 1;
-    PackJob jobs[PACK_MAX_THREADS];
-    pthread_t tids[PACK_MAX_THREADS];
-    int started[PACK_MAX_THREADS];
-    const Py_ssize_t chunk = (n + threads - 1) / threads;
-    for (int t = 0; t < threads; ++t) {
-        Py_ssize_t b = t * chunk, e = b + chunk > n ? n : b + chunk;
-        if (b > n) b = n;
-        jobs[t] = (PackJob){items, b, e, words, dst, mod, slow};
-        started[t] = 0;
-        if (t > 0) started[t] = pthread_create(&tids[t], NULL, pack_worker, &jobs[t]) == 0;
+/* make sure workers 1 .. want-1 exist; returns the number of jobs that can run in parallel (>= 1) */
+static int pool_ensure(int want) {
+    if (g_pool.owner != getpid()) {   /* first use, or a forked child: the parent's threads do not exist here */
+        pthread_mutex_init(&g_pool.mu, NULL);
+        pthread_cond_init(&g_pool.wake, NULL);
+        pthread_cond_init(&g_pool.done, NULL);
+        g_pool.n_workers = 0;
+        g_pool.generation = 0;
+        g_pool.owner = getpid();
     }
-    pack_worker(&jobs[0]);
-    for (int t = 1; t < threads; ++t) {
-        if (started[t]) pthread_join(tids[t], NULL);
-        else pack_worker(&jobs[t]);
+    while (g_pool.n_workers < want - 1) {
+        pthread_attr_t attr;
+        pthread_attr_init(&attr);
+        pthread_attr_setdetachstate(&attr, PTHREAD_CREATE_DETACHED);
+        const int id = g_pool.n_workers + 1;
+        const int rc = pthread_create(&g_pool.tids[id], &attr, pool_main, (void*)(intptr_t)id);
+        pthread_attr_destroy(&attr);
+        if (rc != 0) break;
+        g_pool.n_workers = id;
     }
+    return g_pool.n_workers + 1;
 }
 
-/* ints_to_limbs(seq, words, modulus_or_None, out) -> None.  out: writable buffer of len(seq) * words * 8 bytes. */
+/* elements [begin, end) of items; returns 1 when some element was left to the general path */
+static int pack_fast(PyObject** items, Py_ssize_t begin, Py_ssize_t end, size_t words, unsigned char* dst, const uint64_t* mod, unsigned char* slow) {
+    const Py_ssize_t n = end - begin;
+    int threads = n >= PACK_PARALLEL_MIN ? pack_threads() : 1;
+    if (threads > 1) threads = pool_ensure(threads) < threads ? g_pool.n_workers + 1 : threads;
+    PackJob jobs[PACK_MAX_THREADS];
+    const Py_ssize_t chunk = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; ++t) {
+        Py_ssize_t b = begin + t * chunk, e = b + chunk > end ? end : b + chunk;
+        if (b > end) b = end;
+        jobs[t] = (PackJob){items, b, e, words, dst, mod, slow, 0};
+    }
+    if (threads > 1) {
+        pthread_mutex_lock(&g_pool.mu);
+        g_pool.jobs = jobs;
+        g_pool.n_jobs = threads;
+        g_pool.finished = 0;
+        ++g_pool.generation;
+        pthread_cond_broadcast(&g_pool.wake);
+        pthread_mutex_unlock(&g_pool.mu);
+    }
+    pack_worker(&jobs[0]);
+    if (threads > 1) {
+        pthread_mutex_lock(&g_pool.mu);
+        while (g_pool.finished < threads - 1) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+        g_pool.n_jobs = 0;
+        pthread_mutex_unlock(&g_pool.mu);
+    }
+    int any = 0;
+    for (int t = 0; t < threads; ++t) any |= jobs[t].any_slow;
+    return any;
+}
+
+/* ints_to_limbs(seq, words, modulus_or_None, out[, begin, end]) -> None.  Elements [begin, end) of seq (default: all) go to
+ * rows [begin, end) of out, a writable buffer of len(seq) * words * 8 bytes: a caller can convert a long list chunk by
+ * chunk -- and ship every chunk while the next one is converted -- without slicing the list (a slice copies the pointers
+ * and touches every reference count). */
 static PyObject* ints_to_limbs(PyObject* self, PyObject* args) {
     PyObject *seq, *modulus;
-    Py_ssize_t words;
+    Py_ssize_t words, begin = 0, end = -1;
     Py_buffer out;
-    if (!PyArg_ParseTuple(args, "OnOw*", &seq, &words, &modulus, &out)) return NULL;
+    if (!PyArg_ParseTuple(args, "OnOw*|nn", &seq, &words, &modulus, &out, &begin, &end)) return NULL;
     PyObject* fast = PySequence_Fast(seq, "expected a sequence of ints");
     if (!fast) { PyBuffer_Release(&out); return NULL; }
     const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
@@ -120,6 +222,9 @@ static PyObject* ints_to_limbs(PyObject* self, PyObject* args) {
     PyObject* result = NULL;
     PyObject* mod_obj = NULL;   /* the modulus as an exact int (new reference) */
     unsigned char* slow = NULL;
+    if (end < 0 || end > n) end = n;
+    if (begin < 0) begin = 0;
+    if (begin > end) begin = end;
     if ((size_t)out.len < (size_t)n * nbytes || nbytes > sizeof(mod_bytes) || words < 1) {
         PyErr_SetString(PyExc_ValueError, "output buffer too small");
         goto done;
@@ -138,8 +243,8 @@ static PyObject* ints_to_limbs(PyObject* self, PyObject* args) {
     slow = (unsigned char*)malloc(n > 0 ? (size_t)n : 1);
     if (!slow) { PyErr_NoMemory(); goto done; }
     memcpy(mod_words, mod_bytes, have_mod ? nbytes : 0);
-    pack_fast(PySequence_Fast_ITEMS(fast), n, (size_t)words, dst, have_mod ? mod_words : NULL, slow);
-    for (Py_ssize_t i = 0; i < n; ++i) {
+    if (!pack_fast(PySequence_Fast_ITEMS(fast), begin, end, (size_t)words, dst, have_mod ? mod_words : NULL, slow)) begin = end;  /* nothing flagged */
+    for (Py_ssize_t i = begin; i < end; ++i) {
         if (!slow[i]) continue;
         PyObject* item = PySequence_Fast_GET_ITEM(fast, i);
         PyObject* v = PyNumber_Index(item);  /* accepts numpy integers too; new reference */
@@ -216,7 +321,7 @@ done:
 }
 
 static PyMethodDef methods[] = {
-    {"ints_to_limbs", ints_to_limbs, METH_VARARGS, "ints_to_limbs(seq, words, modulus_or_None, out_buffer)"},
+    {"ints_to_limbs", ints_to_limbs, METH_VARARGS, "ints_to_limbs(seq, words, modulus_or_None, out_buffer[, begin, end])"},
     {"limbs_to_ints", limbs_to_ints, METH_VARARGS, "limbs_to_ints(buffer, words) -> list of ints"},
     {NULL, NULL, 0, NULL}};
 
