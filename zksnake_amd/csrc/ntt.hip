@@ -60,6 +60,143 @@ __global__ void powers_kernel(uint32_t* out, Fp<P> g, uint32_t count) {
     for (int i = 0; i < P::W / 4; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 
+// ---- lazy-range arithmetic of the butterfly passes ---------------------------------------------------------------
+// A radix-4 step of the passes below used to spend a fifth of its VALU instructions on four range-selecting additions
+// (fp_add: two candidate results carried through one pass, then a select).  Inside a pass the values now live in a wider
+// range instead: every element of the LDS tile is NORMALISED (limbs < 2^29) with value < 9p, sums are formed limb by limb
+// without carries, and only the one output per step that is a sum of sums is brought back -- by ONE estimated multiple of
+// 8p and a signed carry pass.  For a step on (x00, x01, x10, x11), all < 9p:
+//     a0 = x00 + x10, b0 = x01 + x11             limb-wise: limbs < 2^30, value < 18p
+//     a1 = w (x00 - x10 + 18p*), b1 = w' (..)    operand limbs < 3 2^29, value < 27p; product < 2p, normalised
+//     x00' = reduce8(a0 + b0)                    limbs < 2^31, value < 36p  ->  normalised, < 8.7p
+//     x01' = w2 (a0 - b0 + 36p*)                 operand limbs < 5 2^29, value < 54p: columns 9 (5 + 1) 2^58 < 2^64
+//     x10' = normalise(a1 + b1)                  < 4p
+//     x11' = w2 (a1 - b1 + 4p*)                  as before
+// (kp* = k p written with borrow-proof limbs).  A Montgomery product needs (a/p)(b/p) <= R/p = 2^261/p (168 for BN254 Fr,
+// 70.7 for BLS12-381 Fr): the twiddles of the 9-word table are canonical (< p), so 54 * 1 fits both fields.
+// tools/model_lazy_ntt.py replays these steps on integers with the limb and column bounds asserted.
+
+// k p as normalised 29-bit limbs, at compile time
+template <class P>
+struct LimbConst { uint32_t v[P::N]; };
+template <class P>
+constexpr LimbConst<P> times_p(uint32_t k) {
+    LimbConst<P> r{};
+    uint64_t carry = 0;
+    for (int i = 0; i < P::N; ++i) {
+        const uint64_t t = (uint64_t)P::M[i] * k + carry;
+        r.v[i] = i < P::N - 1 ? (uint32_t)(t & LIMB_MASK) : (uint32_t)t;
+        carry = t >> LIMB_BITS;
+    }
+    return r;
+}
+
+// a + b, limb by limb (no carries): the caller accounts for the limb width
+template <class P>
+__device__ __forceinline__ Fp<P> lz_add(const Fp<P>& a, const Fp<P>& b) {
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+
+// a - b + K p with borrow-proof limbs: every limb of K p but the top one borrows 2^BITS from the limb above, so no limb goes
+// negative for b with limbs < 2^BITS and value <= K p / 2.  One operand of a product only.
+template <class P, int K, int BITS>
+__device__ __forceinline__ Fp<P> lz_sub(const Fp<P>& a, const Fp<P>& b) {
+    constexpr LimbConst<P> kp = times_p<P>(K);
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        const uint32_t c = kp.v[i] + (i < P::N - 1 ? (1u << BITS) : 0u) - (i > 0 ? (1u << (BITS - LIMB_BITS)) : 0u);
+        r.v[i] = a.v[i] + c - b.v[i];
+    }
+    return r;
+}
+
+// carry pass: limbs < 2^31 in, normalised limbs out, same value
+template <class P>
+__device__ __forceinline__ Fp<P> lz_norm(const Fp<P>& a) {
+    Fp<P> r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        const uint32_t t = a.v[i] + c;
+        if (i < P::N - 1) {
+            r.v[i] = t & LIMB_MASK;
+            c = t >> LIMB_BITS;
+        } else {
+            r.v[i] = t;
+        }
+    }
+    return r;
+}
+
+// a - k U p for the estimate k = floor(top(a) / (top(U p) + 1)) (one multiply-high), then a signed carry pass: limbs < 2^31 and
+// value < 4.5 U p in, normalised limbs and value < 1.09 U p out (k <= 4, so k * limb(U p) < 2^31 and every limb difference
+// fits a signed 32-bit register).  U = 8 inside a pass, U = 2 on the way to a canonical result.
+template <class P, int U>
+__device__ __forceinline__ Fp<P> lz_reduce(const Fp<P>& a) {
+    constexpr int N = P::N;
+    constexpr LimbConst<P> up = times_p<P>(U);
+    constexpr uint32_t MAGIC = (uint32_t)((1ull << 32) / ((uint64_t)up.v[N - 1] + 1));
+    const uint32_t t = a.v[N - 1] + (a.v[N - 2] >> LIMB_BITS);
+    const uint32_t k = __umulhi(t, MAGIC);
+    Fp<P> r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int32_t d = (int32_t)(a.v[i] - k * up.v[i]) + c;
+        if (i < N - 1) {
+            r.v[i] = (uint32_t)d & LIMB_MASK;
+            c = d >> LIMB_BITS;
+        } else {
+            r.v[i] = (uint32_t)d;
+        }
+    }
+    return r;
+}
+
+// normalised, value < 9p  ->  canonical: one estimated multiple of 2p, then two conditional subtractions of p
+template <class P>
+__device__ __forceinline__ Fp<P> lz_canonical(const Fp<P>& a) {
+    return fp_reduce_full<P>(fp_reduce_full<P>(lz_reduce<P, 2>(a)));
+}
+
+// an element as NINE raw limb words (36 bytes): the twiddle table of the passes and the scratch vectors between two passes
+// keep register form, so that neither side pays the 8-word pack / unpack (78 VALU instructions per radix-4 step for the three
+// twiddles alone) and values above 2^256 (< 9p between passes) have room
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+template <class P>
+__device__ __forceinline__ Fp<P> load_limbs9(const uint32_t* p) {
+    static_assert(P::N == 9, "scalar fields of nine 29-bit limbs");
+    Fp<P> r;
+    const u32x4_a4 a = *reinterpret_cast<const u32x4_a4*>(p), b = *reinterpret_cast<const u32x4_a4*>(p + 4);
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    r.v[8] = p[8];
+    return r;
+}
+template <class P>
+__device__ __forceinline__ void store_limbs9(uint32_t* p, const Fp<P>& a) {
+    u32x4_a4 x, y;
+    x.x = a.v[0]; x.y = a.v[1]; x.z = a.v[2]; x.w = a.v[3];
+    y.x = a.v[4]; y.y = a.v[5]; y.z = a.v[6]; y.w = a.v[7];
+    *reinterpret_cast<u32x4_a4*>(p) = x;
+    *reinterpret_cast<u32x4_a4*>(p + 4) = y;
+    p[8] = a.v[8];
+}
+constexpr int TW_WORDS = 9;   // words per entry of the stage-major twiddle table and of a scratch element
+
+// stage-major twiddle table in 9-word form: canonical Montgomery representatives (< p), see the range notes above
+template <class P>
+__global__ void twiddle9_kernel(uint32_t* out, Fp<P> zeta, uint32_t count) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    uint32_t e[1] = {k};
+    store_limbs9<P>(out + (size_t)k * TW_WORDS, fp_reduce_full<P>(fp_pow<P>(zeta, e, 1)));
+}
+
 // ---- butterfly passes -----------------------------------------------------------------------
 // Decimation in frequency with the digit reversal folded into the passes.  Before a pass, `done` low bits of the
 // physical index hold finished (bit-reversed) frequency digits and the upper rem = log_n - done bits the remaining
@@ -70,14 +207,16 @@ __global__ void powers_kernel(uint32_t* out, Fp<P> g, uint32_t count) {
 // i.e. D's frequency digit lands just above the digits already finished.  After the last pass the vector is in natural
 // order: no scattered final store, no separate reordering pass.  `in` and `out` must be different vectors unless the
 // pass is the only one (a single workgroup that reads everything before it writes).
-// The last pass multiplies by `scale` when use_scale != 0 (1/N of the inverse transform) and stores canonical values;
-// the other passes keep values semi-reduced (< 2p).
+// Element formats: the first pass reads canonical 8-word elements, the last pass writes them (multiplied by `scale` when
+// use_scale != 0: 1/N of the inverse transform); between two passes the elements travel as nine raw limb words with values
+// below 9p (in_raw / out_raw), see the range notes above.
 template <class P>
 __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(const uint32_t* in, uint32_t* out,
                                                                const uint32_t* __restrict__ tw, int log_n,
-                                                               int rem, int m, int q, int final_pass, Fp<P> scale, int use_scale) {
+                                                               int rem, int m, int q, int in_raw, int final_pass, Fp<P> scale, int use_scale) {
     constexpr int N = P::N;  // register limbs (LDS is limb-major)
-    constexpr int W = P::W;  // words per element in HBM
+    constexpr int W = P::W;  // words per canonical element in HBM
+    constexpr int T = TW_WORDS;
     extern __shared__ uint32_t lds[];  // [N][tile]
     const int done = log_n - rem;
     const int tile_log = m + q;
@@ -94,7 +233,7 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(c
     for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
         const uint32_t d = e >> q, r = e & qmask;
         const uint32_t p = (d << rest_bits) | rest0 | r;
-        Fp<P> x = load_fr<P>(in + (size_t)p * W);
+        Fp<P> x = in_raw ? load_limbs9<P>(in + (size_t)p * T) : load_fr<P>(in + (size_t)p * W);
         const uint32_t le = LIDX(e);
 #pragma unroll
         for (int l = 0; l < N; ++l) lds[l * row + le] = x.v[l];
@@ -108,7 +247,7 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(c
     if (m & 1) {
         const int s = rem - m + b;
         const int pos = b + q;
-        const uint32_t* tws = tw + ((size_t)(1u << s) - 1) * W;
+        const uint32_t* tws = tw + ((size_t)(1u << s) - 1) * T;
         for (uint32_t u = threadIdx.x; u < (tile >> 1); u += NTT_THREADS) {
             const uint32_t e0 = ((u >> pos) << (pos + 1)) | (u & ((1u << pos) - 1));
             const uint32_t e1 = e0 | (1u << pos);
@@ -119,9 +258,9 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(c
             const uint32_t l0 = LIDX(e0), l1 = LIDX(e1);
 #pragma unroll
             for (int l = 0; l < N; ++l) { x.v[l] = lds[l * row + l0]; y.v[l] = lds[l * row + l1]; }
-            Fp<P> w = load_fr<P>(tws + (size_t)j * W);
-            Fp<P> sum = fp_add<P>(x, y);
-            Fp<P> dif = fp_mul<P>(w, fp_sub_lazy<P>(x, y));  // (x - y + 4p) un-normalized: fine as a product operand
+            Fp<P> w = load_limbs9<P>(tws + (size_t)j * T);
+            Fp<P> sum = lz_reduce<P, 8>(lz_add<P>(x, y));              // < 18p -> < 8.7p
+            Fp<P> dif = fp_mul<P>(w, lz_sub<P, 18, 29>(x, y));         // operand < 27p
 #pragma unroll
             for (int l = 0; l < N; ++l) { lds[l * row + l0] = sum.v[l]; lds[l * row + l1] = dif.v[l]; }
         }
@@ -131,8 +270,8 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(c
     for (; b >= 1; b -= 2) {
         const int s = rem - m + b;          // upper stage of the pair; the lower one is s - 1
         const int pos_lo = b - 1 + q;
-        const uint32_t* tw_hi = tw + ((size_t)(1u << s) - 1) * W;
-        const uint32_t* tw_lo = tw + ((size_t)(1u << (s - 1)) - 1) * W;
+        const uint32_t* tw_hi = tw + ((size_t)(1u << s) - 1) * T;
+        const uint32_t* tw_lo = tw + ((size_t)(1u << (s - 1)) - 1) * T;
         for (uint32_t u = threadIdx.x; u < (tile >> 2); u += NTT_THREADS) {
             const uint32_t e00 = ((u >> pos_lo) << (pos_lo + 2)) | (u & ((1u << pos_lo) - 1));
             const uint32_t e01 = e00 | (1u << pos_lo), e10 = e00 | (2u << pos_lo), e11 = e00 | (3u << pos_lo);
@@ -148,16 +287,16 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(c
                 x00.v[l] = lds[l * row + l00]; x01.v[l] = lds[l * row + l01];
                 x10.v[l] = lds[l * row + l10]; x11.v[l] = lds[l * row + l11];
             }
-            // stage s: (x00, x10) and (x01, x11)
-            Fp<P> a0 = fp_add<P>(x00, x10);
-            Fp<P> a1 = fp_mul<P>(load_fr<P>(tw_hi + (size_t)j0 * W), fp_sub_lazy<P>(x00, x10));
-            Fp<P> b0 = fp_add<P>(x01, x11);
-            Fp<P> b1 = fp_mul<P>(load_fr<P>(tw_hi + (size_t)j1 * W), fp_sub_lazy<P>(x01, x11));
+            // stage s: (x00, x10) and (x01, x11); every input normalised and < 9p (range notes above)
+            Fp<P> a0 = lz_add<P>(x00, x10);
+            Fp<P> a1 = fp_mul<P>(load_limbs9<P>(tw_hi + (size_t)j0 * T), lz_sub<P, 18, 29>(x00, x10));
+            Fp<P> b0 = lz_add<P>(x01, x11);
+            Fp<P> b1 = fp_mul<P>(load_limbs9<P>(tw_hi + (size_t)j1 * T), lz_sub<P, 18, 29>(x01, x11));
             // stage s-1: (a0, b0) and (a1, b1), one twiddle
-            const Fp<P> w2 = load_fr<P>(tw_lo + (size_t)j2 * W);
-            x00 = fp_add<P>(a0, b0);
-            x01 = fp_mul<P>(w2, fp_sub_lazy<P>(a0, b0));
-            x10 = fp_add<P>(a1, b1);
+            const Fp<P> w2 = load_limbs9<P>(tw_lo + (size_t)j2 * T);
+            x00 = lz_reduce<P, 8>(lz_add<P>(a0, b0));
+            x01 = fp_mul<P>(w2, lz_sub<P, 36, 30>(a0, b0));
+            x10 = lz_norm<P>(lz_add<P>(a1, b1));
             x11 = fp_mul<P>(w2, fp_sub_lazy<P>(a1, b1));
 #pragma unroll
             for (int l = 0; l < N; ++l) {
@@ -182,10 +321,13 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(c
 #pragma unroll
         for (int l = 0; l < N; ++l) x.v[l] = lds[l * row + ls];
         if (final_pass) {
-            if (use_scale) x = fp_mul<P>(x, scale);
-            x = fp_reduce_full<P>(x);
+            // 1/N of the inverse transform rides on a product (9 * 1 <= R/p: the result is below 2p); a forward transform
+            // comes down from < 9p by an estimated multiple of 2p
+            x = use_scale ? fp_reduce_full<P>(fp_mul<P>(x, scale)) : lz_canonical<P>(x);
+            store_fr<P>(out + (size_t)po * W, x);
+        } else {
+            store_limbs9<P>(out + (size_t)po * T, x);
         }
-        store_fr<P>(out + (size_t)po * W, x);
     }
 #undef LIDX
 }
@@ -197,7 +339,7 @@ __global__ void coset_scale_kernel(uint32_t* data, const uint32_t* tw, uint32_t 
     if (i >= n) return;
     if (n == 1) return;
     uint32_t half = n >> 1;
-    Fp<P> w = load_fr<P>(tw + ((size_t)(half - 1) + (i & (half - 1))) * P::W);
+    Fp<P> w = load_limbs9<P>(tw + ((size_t)(half - 1) + (i & (half - 1))) * TW_WORDS);
     if (i >= half) w = fp_neg<P>(w);
     Fp<P> a = load_fr<P>(data + (size_t)i * P::W);
     store_fr<P>(data + (size_t)i * P::W, fp_reduce_full<P>(fp_mul<P>(a, w)));
@@ -370,14 +512,14 @@ static int get_twiddles(int curve, int log_n, TwiddleSet* out, hipStream_t strea
     TwiddleSet ts;
     ts.stages = log_n < 16 ? 16 : log_n;  // small transforms share one 2 MiB table
     if (ts.stages > P::TWO_ADICITY) ts.stages = P::TWO_ADICITY;
-    const size_t bytes = (((size_t)1 << ts.stages) - 1) * P::W * 4;
+    const size_t bytes = (((size_t)1 << ts.stages) - 1) * TW_WORDS * 4;
     ZK_HIP(hipMalloc(&ts.fwd, bytes));
     ZK_HIP(hipMalloc(&ts.inv, bytes));
     for (int s = 0; s < ts.stages; ++s) {
         const uint32_t count = 1u << s;
-        const size_t off = ((size_t)count - 1) * P::W;
-        hipLaunchKernelGGL(twiddle_kernel<P>, dim3((count + 255) / 256), dim3(256), 0, stream, ts.fwd + off, host_root<P>(s + 1, false), count);
-        hipLaunchKernelGGL(twiddle_kernel<P>, dim3((count + 255) / 256), dim3(256), 0, stream, ts.inv + off, host_root<P>(s + 1, true), count);
+        const size_t off = ((size_t)count - 1) * TW_WORDS;
+        hipLaunchKernelGGL(twiddle9_kernel<P>, dim3((count + 255) / 256), dim3(256), 0, stream, ts.fwd + off, host_root<P>(s + 1, false), count);
+        hipLaunchKernelGGL(twiddle9_kernel<P>, dim3((count + 255) / 256), dim3(256), 0, stream, ts.inv + off, host_root<P>(s + 1, true), count);
     }
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipStreamSynchronize(stream));
@@ -453,12 +595,12 @@ static int ntt_dev_impl(int curve, int inverse, int log_n, uint32_t* d, hipStrea
     int rc = get_twiddles<P>(curve, log_n, &ts, stream);
     if (rc) return rc;
     const uint32_t* tw = inverse ? ts.inv : ts.fwd;
-    const size_t bytes = ((size_t)1 << log_n) * P::W * 4;
+    const size_t bytes = ((size_t)1 << log_n) * TW_WORDS * 4;   // a scratch vector: nine raw limb words per element
     Fp<P> scale = fp_one<P>();
     if (inverse) {
         uint32_t nn[P::W] = {0};
         nn[0] = 1u << log_n;
-        scale = fp_inv<P>(fp_from_canonical<P>(nn));
+        scale = fp_reduce_full<P>(fp_inv<P>(fp_from_canonical<P>(nn)));   // canonical: the last pass multiplies values < 9p by it
     }
     const int passes = log_n <= NTT_TILE_LOG ? 1 : (log_n + NTT_MAX_DIGIT - 1) / NTT_MAX_DIGIT;
     uint32_t* scratch = nullptr;
@@ -477,7 +619,7 @@ static int ntt_dev_impl(int curve, int inverse, int log_n, uint32_t* d, hipStrea
         const uint32_t tile = 1u << (m + q);
         const size_t lds_bytes = (size_t)P::N * (tile + 32) * 4;
         hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(1u << (rest_bits - q)), dim3(NTT_THREADS), lds_bytes, stream, src, dst, tw, log_n, rem, m, q,
-                           last ? 1 : 0, scale, (last && inverse) ? 1 : 0);
+                           i > 0 ? 1 : 0, last ? 1 : 0, scale, (last && inverse) ? 1 : 0);
         src = dst;
         which ^= 1;
         rem -= m;
