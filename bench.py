@@ -667,6 +667,21 @@ def prove_metric(torch, args, shard_device, world, with_cpu_baseline=False):
         res["cpu_baseline_all_cores"] = {"value": round(secs_all * 1e3, 1), "unit": "ms", "cores": cores, "kind": "port",
                                          "sample": sample + f"; {cores} threads over the NTT butterflies and the MSM windows (rayon-style; "
                                                             f"the host has {os.cpu_count()} logical cores)"}
+    if world > 1:
+        # what the driver's scaling curve is made of: the replicated part (every rank uploads the witness and runs the whole
+        # QAP chain: at 32 B per element a vector crosses one xGMI link at ~2 G elements/s, a transform produces 7 G/s, so
+        # shipping u, v, h between ranks would cost more than recomputing them -- DESIGN.md section 5), the sharded part
+        # (this rank's windows of the five MSMs) and the collective.  Slowest rank's timeline (all ranks are timed alike).
+        tl = res["timeline_ms"]
+        replicated = tl["qap_ms"]
+        sharded = tl["msm_enqueue_ms"] + tl["msm_finish_ms"] + tl["exchange_assemble_ms"] - tl.get("collective_ms", 0.0)
+        res["per_rank_ms"] = {"qap_replicated": round(replicated, 3), "msm_sharded": round(sharded, 3),
+                              "exchange_collective": round(tl.get("collective_ms", 0.0), 3)}
+        res["amdahl_projection"] = {
+            "one_gpu_ms_if_the_sharded_part_scaled_linearly": round(replicated + world * sharded, 3),
+            "speedup_bound_at_infinite_ranks": round((replicated + world * sharded) / replicated, 2),
+            "note": "projection from this run's split, not a measurement: the MSM part also has per-rank fixed costs (bucket reduction, "
+                    "host tail) that do not shrink with the window count"}
     key = f"groth16_prove_bn254_2^{args.prove_log_n}" + (f"_window_sharded_x{world}" if world > 1 else "")
     return {key: res}
 

@@ -242,6 +242,15 @@ int zk_msm_plan_entries(uint64_t handle, uint64_t* entries_per_window);
  * the launch stream(s): [0] digits+sort, [1] bucket accumulation (dominant kernel; summed over its launches),
  * [2] bucket combination + reduction + D2H, [3] host tail, [4] total.  Returns the number of floats written. */
 int zk_msm_plan_timings(uint64_t handle, float* ms, int cap);
+/* Tuning options of one plan (not in the reference: ark's MSM has no knobs).  Defaults come from the ZKMI_* environment
+ * variables read when the plan is created; the run-time ones can be changed between runs of a live plan:
+ *   "segment_lanes"     lanes the accumulate kernel aims at (<= the value at creation, >= 64)        ZKMI_SEG_LANES
+ *   "sum_one_step"      1 = row / column sums of the bucket reduction in one launch                 ZKMI_SUM_ONE_STEP
+ *   "lanes_per_output"  lanes per row / column sum of the one-step form (0 = automatic, 2 .. 64)    ZKMI_LPO
+ *   "two_level_sort"    0 = one-level / bucket-range sorts only (windows <= 16 bits)                ZKMI_NO_TWO_LEVEL
+ * Results never depend on them.  ZK_ERR_ARG for unknown names (including the creation-time options ZKMI_SORT_WGS,
+ * ZKMI_FINE_LOG, ZKMI_NO_GLV, ZKMI_PRE_C), for values the plan cannot honour and while a run is in flight. */
+int zk_msm_plan_set_option(uint64_t handle, const char* name, int64_t value);
 
 /* ---- single-point host arithmetic (PointG1 / PointG2 methods, src/bn254/curve.rs:25-324) -- */
 

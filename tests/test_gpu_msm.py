@@ -520,18 +520,44 @@ def test_shared_sort_between_g1_and_g2_plans(gpu, flags, n):
             N.check(gpu.zk_msm_plan_destroy(h))
 
 
-def test_one_level_sort_path_still_correct(gpu):
-    """the chunked one-level sort now only serves n > 2^24 (and the ZKMI_NO_TWO_LEVEL knob): keep it checked, in a child
-    process because the knob is read once per process"""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ZKMI_NO_TWO_LEVEL="1")
-    for args in (["BN254", "1", "19"], ["BN254", "1", "19", "pre"]):
-        res = subprocess.run([sys.executable, os.path.join(root, "tools", "big_msm_check.py")] + args, env=env,
-                             capture_output=True, text=True, timeout=300)
-        assert res.returncode == 0 and "match=True" in res.stdout, res.stdout + res.stderr
+@pytest.mark.parametrize("flags", [0, N.MSM_PRECOMPUTE])
+def test_plan_options_switch_paths_in_process(gpu, flags):
+    """zk_msm_plan_set_option flips the tuning knobs of ONE live plan (they used to be process-wide environment latches, and
+    this test had to run a child process): the chunked one-level sort (which otherwise only serves n > 2^24), one-step
+    row / column sums, other lane counts -- every combination gives the oracle's point; bad names and values are refused"""
+    cid, grp, n = 0, 1, 1 << 19
+    bases, r = _bases_from_library(gpu, cid, grp, n, 0x0F710)
+    sc = W.splitmix64(0x5CA1A, 4 * n).reshape(n, 4)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)
+    exp = corc.msm(cid, grp, sc, bases, threads=16)
+    h = N._u64(0)
+    N.check(gpu.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, flags, 0, h))
+    try:
+        def run():
+            out = np.zeros(N.point_limbs(cid, grp), dtype=np.uint64)
+            N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, 0, 0, N.u64p(out), None))
+            tm = (N.ctypes.c_float * 5)()
+            gpu.zk_msm_plan_timings(h, tm, 5)
+            return out, list(tm)
+
+        base, _ = run()
+        assert (base == exp).all()
+        for name, value in ((b"two_level_sort", 0), (b"sum_one_step", 1), (b"lanes_per_output", 16), (b"segment_lanes", 65536),
+                            (b"two_level_sort", 1), (b"sum_one_step", 0), (b"lanes_per_output", 0)):
+            N.check(gpu.zk_msm_plan_set_option(h, name, value))
+            out, _ = run()
+            assert (out == exp).all(), (name, value)
+        for name, value in ((b"no_such_option", 1), (b"fine_log", 7), (b"lanes_per_output", 48), (b"segment_lanes", 1 << 30), (b"segment_lanes", 3)):
+            assert gpu.zk_msm_plan_set_option(h, name, value) == N.ZK_ERR_ARG, (name, value)
+        # not while a run is in flight
+        N.check(gpu.zk_msm_plan_enqueue(h, n, sc.ctypes.data, 0, 0, 0, N.STREAM_PLAN))
+        assert gpu.zk_msm_plan_set_option(h, b"sum_one_step", 1) == N.ZK_ERR_ARG
+        out = np.zeros(N.point_limbs(cid, grp), dtype=np.uint64)
+        N.check(gpu.zk_msm_plan_finish(h, N.u64p(out)))
+        assert (out == exp).all()
+    finally:
+        N.check(gpu.zk_msm_plan_destroy(h))
+    assert gpu.zk_msm_plan_set_option(h, b"sum_one_step", 1) == N.ZK_ERR_ARG     # unknown handle
 
 
 @pytest.mark.parametrize("flags", [0, 1])

@@ -95,6 +95,7 @@ SIGNATURES = {
     "zk_msm_window_layout": (_i, [_i, _i, _u64, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "zk_msm_plan_entries": (_i, [_u64, ctypes.POINTER(_u64)]),
     "zk_msm_plan_timings": (_i, [_u64, ctypes.POINTER(ctypes.c_float), _i]),
+    "zk_msm_plan_set_option": (_i, [_u64, ctypes.c_char_p, ctypes.c_int64]),
     "zk_point_add": (_i, [_i, _i, _u64p, _u64p, _u64p]),
     "zk_point_neg": (_i, [_i, _i, _u64p, _u64p]),
     "zk_point_sum": (_i, [_i, _i, _u64, _u64p, _u64p]),

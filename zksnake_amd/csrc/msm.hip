@@ -134,6 +134,13 @@ int zk_msm_plan_enqueue_shared(uint64_t handle, uint64_t lender_handle, void* st
     return p->enqueue_shared(lender, pick_stream(p, stream));
 }
 
+int zk_msm_plan_set_option(uint64_t handle, const char* name, int64_t value) {
+    MsmPlanBase* p = find_plan(handle);
+    if (!p) return fail(ZK_ERR_ARG, "unknown MSM plan handle");
+    if (!name) return fail(ZK_ERR_ARG, "option name is NULL");
+    return p->set_option(name, value);
+}
+
 int zk_msm_plan_finish(uint64_t handle, uint64_t* out) {
     MsmPlanBase* p = find_plan(handle);
     if (!p) return fail(ZK_ERR_ARG, "unknown MSM plan handle");

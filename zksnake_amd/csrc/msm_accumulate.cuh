@@ -1,0 +1,87 @@
+// msm_accumulate.cuh -- stage 5 of the MSM pipeline, the dominant kernel (bucket accumulation over uniform segments of the
+// sorted entry list), and the conversion of the bases to Montgomery form.  Pipeline overview: msm_impl.cuh.
+#pragma once
+#include "msm_common.cuh"
+
+namespace zkmi {
+
+// ---- 5. accumulate (dominant kernel) ----------------------------------------------------------------
+
+// where lane t's run of bucket `key` goes: a bucket that lies within ONE segment has one run, which is the bucket sum itself
+// and is written straight to the bucket array (combine_kernel skips such buckets); otherwise the run's slot in `partials`
+template <class F>
+__device__ __forceinline__ uint32_t* run_slot(uint32_t* partials, uint32_t* buckets, const uint32_t* run_start, const uint32_t* bucket_start,
+                                              uint32_t key, uint32_t t, uint32_t seg_len) {
+    constexpr int XW = 4 * F::LIMBS;
+    const uint32_t r0 = run_start[key];
+    if (run_start[key + 1] - r0 == 1) return buckets + (size_t)key * XW;
+    return partials + (size_t)(r0 + t - bucket_start[key] / seg_len) * XW;
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void accumulate_kernel(const uint32_t* __restrict__ bases,
+                                                         const uint32_t* __restrict__ sorted,
+                                                         const uint32_t* __restrict__ bucket_start,
+                                                         const uint32_t* __restrict__ run_start, uint32_t n_keys,
+                                                         uint32_t seg_len, uint32_t* __restrict__ partials,
+                                                         uint32_t* __restrict__ buckets) {
+    typedef typename G::F F;
+    constexpr int AW = 2 * F::LIMBS;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = bucket_start[n_keys];
+    const uint32_t begin = t * seg_len;
+    if (begin >= total) return;
+    uint32_t end = begin + seg_len;
+    if (end > total) end = total;
+    // bucket of the first entry: largest key with bucket_start[key] <= begin (its end is > begin)
+    uint32_t lo = 0, hi = n_keys;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (bucket_start[mid] <= begin) lo = mid; else hi = mid;
+    }
+    uint32_t key = lo;
+    uint32_t next = bucket_start[key + 1];
+    XYZZ<F> acc = xyzz_inf<F>();
+    for (uint32_t e = begin; e < end; ++e) {
+        if (e == next) {
+            // the bucket ends inside this segment: flush its run, move to the next non-empty bucket
+            store_xyzz<F>(run_slot<F>(partials, buckets, run_start, bucket_start, key, t, seg_len), acc);
+            acc = xyzz_inf<F>();
+            do {
+                ++key;
+                next = bucket_start[key + 1];
+            } while (next <= e);
+        }
+        uint32_t ref = sorted[e];
+        const uint32_t* src = bases + (size_t)(ref & 0x7FFFFFFFu) * AW;
+        xyzz_add_affine_mem<F>(acc, src, (ref >> 31) != 0);
+    }
+    store_xyzz<F>(run_slot<F>(partials, buckets, run_start, bucket_start, key, t, seg_len), acc);
+}
+
+// ---- bases: canonical -> Montgomery; batch scalar multiplication -------------------------------------
+
+// glv != 0: rows 2i = P_i and 2i + 1 = phi(P_i) = (beta x, y)
+template <class G>
+__global__ void bases_to_mont_kernel(const uint32_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ out, int glv) {
+    typedef typename G::F F;
+    constexpr int AW = 2 * F::LIMBS;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[AW];
+    load_words<AW>(w, in + i * AW);
+    Affine<F> p;
+    p.x = F::from_canonical(w);
+    p.y = F::from_canonical(w + F::LIMBS);
+    if constexpr (GlvOf<G>::OK) {
+        if (glv) {
+            store_affine<F>(out + 2 * i * AW, p);
+            p.x = F::mul(p.x, F::from_canonical(GlvOf<G>::P::BETA));
+            store_affine<F>(out + (2 * i + 1) * AW, p);
+            return;
+        }
+    }
+    store_affine<F>(out + i * AW, p);
+}
+
+}  // namespace zkmi

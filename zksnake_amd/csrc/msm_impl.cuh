@@ -35,1166 +35,14 @@
 #include "codec.cuh"
 #include "glv_params.h"
 
-namespace zkmi {
-
-
-// ---- device load/store of field elements / points (packed u32 words, 16-byte vectors) ------
-
-template <int WORDS>
-__device__ __forceinline__ void load_words(uint32_t* dst, const uint32_t* src) {
-    const uint4* q = reinterpret_cast<const uint4*>(src);
-#pragma unroll
-    for (int i = 0; i < WORDS / 4; ++i) {
-        uint4 t = q[i];
-        dst[4 * i] = t.x; dst[4 * i + 1] = t.y; dst[4 * i + 2] = t.z; dst[4 * i + 3] = t.w;
-    }
-}
-template <int WORDS>
-__device__ __forceinline__ void store_words(uint32_t* dst, const uint32_t* src) {
-    uint4* q = reinterpret_cast<uint4*>(dst);
-#pragma unroll
-    for (int i = 0; i < WORDS / 4; ++i) q[i] = make_uint4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
-}
-
-// Points in memory are packed 32-bit words (LIMBS per coordinate); registers hold 29-bit limbs.
-template <class F>
-__device__ __forceinline__ Affine<F> load_affine(const uint32_t* p) {
-    uint32_t w[2 * F::LIMBS];
-    load_words<2 * F::LIMBS>(w, p);
-    return {F::load(w), F::load(w + F::LIMBS)};
-}
-template <class F>
-__device__ __forceinline__ void store_affine(uint32_t* p, const Affine<F>& a) {
-    uint32_t w[2 * F::LIMBS];
-    F::store(w, a.x);
-    F::store(w + F::LIMBS, a.y);
-    store_words<2 * F::LIMBS>(p, w);
-}
-template <class F>
-__device__ __forceinline__ XYZZ<F> load_xyzz(const uint32_t* p) {
-    uint32_t w[4 * F::LIMBS];
-    load_words<4 * F::LIMBS>(w, p);
-    return {F::load(w), F::load(w + F::LIMBS), F::load(w + 2 * F::LIMBS), F::load(w + 3 * F::LIMBS)};
-}
-template <class F>
-__device__ __forceinline__ void store_xyzz(uint32_t* p, const XYZZ<F>& a) {
-    uint32_t w[4 * F::LIMBS];
-    F::store(w, a.X);
-    F::store(w + F::LIMBS, a.Y);
-    F::store(w + 2 * F::LIMBS, a.ZZ);
-    F::store(w + 3 * F::LIMBS, a.ZZZ);
-    store_words<4 * F::LIMBS>(p, w);
-}
-template <class F>
-static XYZZ<F> load_xyzz_host(const uint32_t* w) {
-    return {F::load(w), F::load(w + F::LIMBS), F::load(w + 2 * F::LIMBS), F::load(w + 3 * F::LIMBS)};
-}
-
-// register-form copies (LDS staging, wave shuffles): XYZZ<F> is a plain struct of u32 registers
-template <class F>
-struct XyzzRegs { static constexpr int COUNT = sizeof(XYZZ<F>) / 4; };
-
-template <class F>
-__device__ __forceinline__ XYZZ<F> shfl_xor_xyzz(const XYZZ<F>& a, int mask) {
-    XYZZ<F> r;
-    const uint32_t* s = reinterpret_cast<const uint32_t*>(&a);
-    uint32_t* d = reinterpret_cast<uint32_t*>(&r);
-#pragma unroll
-    for (int i = 0; i < XyzzRegs<F>::COUNT; ++i) d[i] = __shfl_xor(s[i], mask, 64);
-    return r;
-}
-template <class F>
-__device__ __forceinline__ void lds_put_xyzz(uint32_t* slot, const XYZZ<F>& a) {
-    const uint32_t* s = reinterpret_cast<const uint32_t*>(&a);
-#pragma unroll
-    for (int i = 0; i < XyzzRegs<F>::COUNT; ++i) slot[i] = s[i];
-}
-template <class F>
-__device__ __forceinline__ XYZZ<F> lds_get_xyzz(const uint32_t* slot) {
-    XYZZ<F> r;
-    uint32_t* d = reinterpret_cast<uint32_t*>(&r);
-#pragma unroll
-    for (int i = 0; i < XyzzRegs<F>::COUNT; ++i) d[i] = slot[i];
-    return r;
-}
-
-// Buckets with more than COMBINE_SMALL_MAX runs (skewed scalars: e.g. the short top window, or many equal
-// scalars) are listed in big_list and reduced by a whole workgroup each instead of one lane.
-constexpr uint32_t COMBINE_SMALL_MAX = 16;    // <= 16 runs: one lane adds them up
-constexpr uint32_t COMBINE_WAVE_MAX = 2048;   // <= 2048 runs: one wave per bucket; above: one workgroup
-
-
-// ---- G1 endomorphism (GLV) ---------------------------------------------------------------------------
-// General (not fixed-base) G1 plans run the MSM over 2n points (P_i, phi(P_i)) with the two ~127-bit halves of every
-// scalar, k = k1 + lambda k2: the same number of bucket additions (2n entries in half the windows), but half the bucket
-// sets to reduce and half the doublings in the host tail.  Constants and the decomposition: tools/gen_glv_params.py.
-template <class G> struct GlvOf { static constexpr bool OK = false; };
-template <> struct GlvOf<Bn254G1> { static constexpr bool OK = true; typedef Bn254Glv P; };
-template <> struct GlvOf<Bls381G1> { static constexpr bool OK = true; typedef Bls381Glv P; };
-
+#include "msm_common.cuh"
 #if !defined(ZK_PART) || ZK_PART == 0  // sort-stage kernels and the plan live in part 0 only
-// ---- 1. digits -----------------------------------------------------------------------------------
+#include "msm_sort.cuh"
+#endif
+#include "msm_accumulate.cuh"
+#include "msm_reduce.cuh"
 
-struct DigitBias {
-    uint32_t v[13];  // bias limbs (up to 12 + 1)
-};
-
-// eight consecutive digits of a row as 32-bit values (rows are padded to 8 digits and 16-byte aligned)
-template <class DIG>
-__device__ __forceinline__ void load8_digits(const DIG* p, uint32_t* v);
-template <>
-__device__ __forceinline__ void load8_digits<uint16_t>(const uint16_t* p, uint32_t* v) {
-    const uint4 pk = *reinterpret_cast<const uint4*>(p);
-    const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = (w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
-}
-template <>
-__device__ __forceinline__ void load8_digits<uint32_t>(const uint32_t* p, uint32_t* v) {
-    const uint4 a = reinterpret_cast<const uint4*>(p)[0], b = reinterpret_cast<const uint4*>(p)[1];
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-
-// DIG = uint16_t for windows up to 16 bits, uint32_t for the wider windows of fixed-base plans
-template <class FrP, class DIG>
-__global__ void digits_kernel(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t dstride, int c, int w_first, int w_count,
-                              DigitBias bias, DIG* __restrict__ dig, uint32_t* __restrict__ big_count) {
-    constexpr int N = FrP::W;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) big_count[0] = big_count[1] = 0;  // consumed by runs_scan_block_kernel later in the same stream
-    if (i >= n) return;
-    uint32_t s[N + 1];
-    load_words<N>(s, scalars + (size_t)i * N);
-    // Fr::from(BigUint) semantics: reduce below r
-    for (int k = 0; k < 10; ++k) {
-        uint32_t t[N];
-        if (fp_sub_mod_raw<FrP>(t, s)) break;
-#pragma unroll
-        for (int l = 0; l < N; ++l) s[l] = t[l];
-    }
-    uint64_t carry = 0;
-#pragma unroll
-    for (int l = 0; l < N; ++l) {
-        uint64_t t = (uint64_t)s[l] + bias.v[l] + carry;
-        s[l] = (uint32_t)t;
-        carry = t >> 32;
-    }
-    s[N] = (uint32_t)carry + bias.v[N];
-    const uint32_t mask = (1u << c) - 1;
-    for (int w = w_first; w < w_first + w_count; ++w) {  // only the windows of this run (a rank's share when sharded)
-        int bit = w * c;
-        int word = bit >> 5, off = bit & 31;
-        uint64_t two = (uint64_t)s[word];
-        if (word + 1 <= N) two |= (uint64_t)s[word + 1] << 32;
-        uint32_t u = (uint32_t)(two >> off) & mask;
-        dig[(size_t)w * dstride + i] = (DIG)u;  // rows padded to 8 digits: 16-byte aligned vector reads
-    }
-}
-
-// NA x NB words -> NA + NB words
-template <int NA, int NB>
-__device__ __forceinline__ void mul_words(uint32_t* out, const uint32_t* a, const uint32_t* b) {
-#pragma unroll
-    for (int k = 0; k < NA + NB; ++k) out[k] = 0;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        uint64_t carry = 0;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const uint64_t t = (uint64_t)a[i] * b[j] + out[i + j] + carry;
-            out[i + j] = (uint32_t)t;
-            carry = t >> 32;
-        }
-        out[i + NB] = (uint32_t)carry;
-    }
-}
-// acc (4 words) -= a * b mod 2^128
-__device__ __forceinline__ void submul_lo4(uint32_t* acc, const uint32_t* a, const uint32_t* b) {
-    uint32_t p[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        uint64_t carry = 0;
-#pragma unroll
-        for (int j = 0; j + i < 4; ++j) {
-            const uint64_t t = (uint64_t)a[i] * b[j] + p[i + j] + carry;
-            p[i + j] = (uint32_t)t;
-            carry = t >> 32;
-        }
-    }
-    uint64_t borrow = 0;
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-        const uint64_t t = (uint64_t)acc[l] - p[l] - borrow;
-        acc[l] = (uint32_t)t;
-        borrow = (t >> 32) & 1;
-    }
-}
-// (k g + 2^319) >> 320, four words
-__device__ __forceinline__ void glv_round_quotient(uint32_t* c, const uint32_t* k8, const uint32_t* g7) {
-    uint32_t prod[15];
-    mul_words<8, 7>(prod, k8, g7);
-    uint64_t carry = 0x80000000ull;  // 2^319 = bit 31 of word 9
-#pragma unroll
-    for (int l = 9; l < 15; ++l) {
-        const uint64_t t = (uint64_t)prod[l] + carry;
-        prod[l] = (uint32_t)t;
-        carry = t >> 32;
-    }
-#pragma unroll
-    for (int l = 0; l < 4; ++l) c[l] = prod[10 + l];
-}
-
-// digits of the two halves of every scalar: entry 2i carries k1 (against P_i), entry 2i + 1 carries k2 (against phi(P_i)).
-// The halves are signed; a signed value plus the bias is still a plain string of c-bit fields.
-template <class FrP>
-__global__ void glv_digits_kernel(const uint32_t* __restrict__ scalars, uint32_t m, uint32_t dstride, int c, int w_first, int w_count,
-                                  DigitBias bias, GlvConsts K, uint16_t* __restrict__ dig, uint32_t* __restrict__ big_count) {
-    constexpr int N = FrP::W;
-    static_assert(N == 8, "scalar fields of 8 words");
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) big_count[0] = big_count[1] = 0;
-    if (i >= m) return;
-    uint32_t s[N];
-    load_words<N>(s, scalars + (size_t)i * N);
-    for (int k = 0; k < 10; ++k) {
-        uint32_t t[N];
-        if (fp_sub_mod_raw<FrP>(t, s)) break;
-#pragma unroll
-        for (int l = 0; l < N; ++l) s[l] = t[l];
-    }
-    uint32_t c1[4], c2[4];
-    glv_round_quotient(c1, s, K.g1);
-    glv_round_quotient(c2, s, K.g2);
-    uint32_t k1[4] = {s[0], s[1], s[2], s[3]}, k2[4] = {0, 0, 0, 0};
-    submul_lo4(k1, c1, K.a1);
-    submul_lo4(k1, c2, K.a2);
-    submul_lo4(k2, c1, K.b1);
-    submul_lo4(k2, c2, K.b2);
-    uint32_t t1[6], t2[6];
-    {
-        const uint32_t e1 = (k1[3] >> 31) ? 0xFFFFFFFFu : 0u, e2 = (k2[3] >> 31) ? 0xFFFFFFFFu : 0u;
-        uint64_t ca = 0, cb = 0;
-#pragma unroll
-        for (int l = 0; l < 5; ++l) {
-            const uint64_t a = (uint64_t)(l < 4 ? k1[l] : e1) + bias.v[l] + ca;
-            const uint64_t b = (uint64_t)(l < 4 ? k2[l] : e2) + bias.v[l] + cb;
-            t1[l] = (uint32_t)a; ca = a >> 32;
-            t2[l] = (uint32_t)b; cb = b >> 32;
-        }
-        t1[5] = t2[5] = 0;
-    }
-    const uint32_t mask = (1u << c) - 1;
-    uint32_t* dig32 = reinterpret_cast<uint32_t*>(dig);
-    for (int w = w_first; w < w_first + w_count; ++w) {
-        const int bit = w * c, word = bit >> 5, off = bit & 31;
-        const uint32_t u1 = (uint32_t)((((uint64_t)t1[word + 1] << 32) | t1[word]) >> off) & mask;
-        const uint32_t u2 = (uint32_t)((((uint64_t)t2[word + 1] << 32) | t2[word]) >> off) & mask;
-        dig32[((size_t)w * dstride >> 1) + i] = u1 | (u2 << 16);
-    }
-}
-
-// ---- 2. histogram / 4. scatter ---------------------------------------------------------------------
-
-constexpr int SORT_THREADS = 1024;
-
-static __global__ __launch_bounds__(SORT_THREADS) void hist_kernel(const uint16_t* __restrict__ dig, uint32_t n, uint32_t dstride, int c,
-                                                            int w_first, int nchunk, uint32_t chunk_len,
-                                                            uint32_t* __restrict__ hist) {
-    extern __shared__ uint32_t lds[];
-    const uint32_t B = 1u << (c - 1);
-    const int wl = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
-    const int w = w_first + wl;
-    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) lds[b] = 0;
-    __syncthreads();
-    uint32_t lo = chunk * chunk_len, hi = lo + chunk_len;
-    if (hi > n) hi = n;
-    const uint16_t* d = dig + (size_t)w * dstride;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
-        int v = (int)d[i] - (int)B;
-        if (v != 0) {
-            uint32_t b = (uint32_t)(v < 0 ? -v : v) - 1;
-            atomicAdd(&lds[b], 1u);
-        }
-    }
-    __syncthreads();
-    uint32_t* out = hist + (size_t)blockIdx.x * B;
-    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) out[b] = lds[b];
-}
-
-// per bucket key: exclusive prefix over the sub-histograms of its group, total, segment count
-static __global__ void prefix_kernel(uint32_t* __restrict__ hist, int group_size, uint32_t B, uint32_t n_keys,
-                              uint32_t* __restrict__ total) {
-    uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
-    if (key >= n_keys) return;
-    uint32_t g = key / B, b = key % B;
-    uint32_t run = 0;
-    for (int h = 0; h < group_size; ++h) {
-        size_t idx = ((size_t)g * group_size + h) * B + b;
-        uint32_t t = hist[idx];
-        hist[idx] = run;
-        run += t;
-    }
-    total[key] = run;
-}
-
-// The sorted entry list is cut into uniform segments of seg_len entries (one lane each), whatever the bucket
-// sizes are.  A "run" is the part of one bucket inside one segment; bucket `key` owns
-//   nruns = 1 + (last_entry / seg_len) - (first_entry / seg_len)   consecutive partial slots.
-// two-level exclusive scan: blocks of 1024
-constexpr int SCAN_BLOCK = 1024;
-static __global__ __launch_bounds__(SCAN_BLOCK) void scan_block_kernel(const uint32_t* __restrict__ in, uint32_t n,
-                                                                uint32_t* __restrict__ out, uint32_t* __restrict__ block_sums) {
-    __shared__ uint32_t sh[SCAN_BLOCK];
-    uint32_t i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    uint32_t v = i < n ? in[i] : 0;
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
-        uint32_t t = threadIdx.x >= (uint32_t)off ? sh[threadIdx.x - off] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
-    }
-    if (i < n) out[i] = sh[threadIdx.x] - v;  // exclusive
-    if (threadIdx.x == SCAN_BLOCK - 1) block_sums[blockIdx.x] = sh[threadIdx.x];
-}
-// the run counts are computed on the fly from the bucket offsets and scanned in the same launch (first level of the
-// run-offset scan); buckets with many runs go to big_list, filled from the front with wave-tier buckets and from the
-// back with workgroup-tier buckets (big_count[0] / big_count[1] are the two lengths, zeroed by digits_kernel)
-static __global__ __launch_bounds__(SCAN_BLOCK) void runs_scan_block_kernel(const uint32_t* __restrict__ bucket_start, uint32_t n_keys,
-                                                                            uint32_t seg_len, uint32_t* __restrict__ out,
-                                                                            uint32_t* __restrict__ block_sums,
-                                                                            uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count) {
-    __shared__ uint32_t sh[SCAN_BLOCK / 64];
-    const uint32_t key = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    uint32_t r = 0;
-    if (key < n_keys) {
-        const uint32_t s0 = bucket_start[key], s1 = bucket_start[key + 1];
-        r = s1 > s0 ? 1 + (s1 - 1) / seg_len - s0 / seg_len : 0;
-        if (r > COMBINE_WAVE_MAX) big_list[n_keys - 1 - atomicAdd(big_count + 1, 1u)] = key;
-        else if (r > COMBINE_SMALL_MAX) big_list[atomicAdd(big_count, 1u)] = key;
-    }
-    // wave-level inclusive scan, then the 16 wave totals
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = r;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(incl, d, 64);
-        if ((int)lane >= d) incl += o;
-    }
-    if (lane == 63) sh[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t w2 = 0; w2 < wave; ++w2) before += sh[w2];
-    if (key < n_keys) out[key] = before + incl - r;  // exclusive
-    if (threadIdx.x == SCAN_BLOCK - 1) block_sums[blockIdx.x] = before + incl;
-}
-// single block: exclusive scan of the block sums in place (n_blocks <= 1024 * 64)
-static __global__ __launch_bounds__(SCAN_BLOCK) void scan_sums_kernel(uint32_t* sums, uint32_t n_blocks, uint32_t* grand_total) {
-    __shared__ uint32_t sh[SCAN_BLOCK];
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < n_blocks; base += SCAN_BLOCK) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < n_blocks ? sums[i] : 0;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
-            uint32_t t = threadIdx.x >= (uint32_t)off ? sh[threadIdx.x - off] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < n_blocks) sums[i] = carry + sh[threadIdx.x] - v;
-        uint32_t blk_total = sh[SCAN_BLOCK - 1];
-        __syncthreads();
-        carry += blk_total;
-    }
-    if (threadIdx.x == 0) *grand_total = carry;
-}
-static __global__ void scan_add_kernel(uint32_t* out, uint32_t n, const uint32_t* block_sums, const uint32_t* grand_total) {
-    uint32_t i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    if (i < n) out[i] += block_sums[blockIdx.x];
-    if (i == 0) out[n] = *grand_total;  // out has n + 1 entries
-}
-
-static __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const uint16_t* __restrict__ dig, uint32_t n, uint32_t dstride, int c,
-                                                               int w_first, int w_count, int nchunk, uint32_t chunk_len,
-                                                               int shared_buckets, uint32_t table_stride, int table_w0,
-                                                               const uint32_t* __restrict__ hist,
-                                                               const uint32_t* __restrict__ bucket_start,
-                                                               uint32_t* __restrict__ sorted) {
-    extern __shared__ uint32_t lds[];
-    const uint32_t B = 1u << (c - 1);
-    // XCD-aware block -> (window, chunk) map: workgroups are dealt round-robin over the 8 XCDs, and all chunks
-    // of one window write 4-byte entries into the same cache lines (the window's bucket regions).  Putting them
-    // on one XCD lets that XCD's L2 merge the partial lines instead of eight caches writing them back separately.
-    int wl, chunk;
-    if (shared_buckets) {
-        wl = blockIdx.x / nchunk;
-        chunk = blockIdx.x % nchunk;
-    } else {
-        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-        wl = x + 8 * (j / nchunk);
-        chunk = j % nchunk;
-        if (wl >= w_count) return;
-    }
-    const int w = w_first + wl;
-    const uint32_t* pre = hist + ((size_t)wl * nchunk + chunk) * B;
-    const uint32_t* start = bucket_start + (shared_buckets ? 0 : (size_t)wl * B);
-    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) lds[b] = start[b] + pre[b];
-    __syncthreads();
-    uint32_t lo = chunk * chunk_len, hi = lo + chunk_len;
-    if (hi > n) hi = n;
-    const uint16_t* d = dig + (size_t)w * dstride;
-    // with shared buckets the point reference addresses the precomputed table row (w, i)
-    const uint32_t ref_base = shared_buckets ? (uint32_t)(w - table_w0) * table_stride : 0;  // table rows start at the plan's first window
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
-        int v = (int)d[i] - (int)B;
-        if (v != 0) {
-            uint32_t b = (uint32_t)(v < 0 ? -v : v) - 1;
-            uint32_t pos = atomicAdd(&lds[b], 1u);
-            sorted[pos] = (ref_base + i) | (v < 0 ? 0x80000000u : 0u);
-        }
-    }
-}
-
-// ---- 2''/4''. two-level counting sort (general mode, large inputs) --------------------------------------
-// The chunked scatter above writes 4-byte references to random bucket regions of its window: every 32-byte sector
-// of `sorted` is touched by several workgroups at different times and goes to HBM as partial writes (8x write
-// amplification, the 0.2 ms of the stage).  Here the sort is split:
-//   level A  (window, chunk) workgroups partition their entries by the COARSE bin = bucket >> fine_log (128 bins per
-//            window at c = 16, fine_log = 8), tile by tile through LDS, so that each bin receives coalesced runs;
-//            an entry travels as one word (sign | low bucket bits | reference);
-//   level B  one workgroup per (bucket set, coarse bin) sorts its entries by the low bits with LDS counters, places
-//            them in an LDS copy of its contiguous slice of `sorted` and writes the slice -- and the bucket offsets --
-//            with coalesced stores.
-// Both levels were first written with direct 4-byte scattered stores and were bound by the L2 request rate (one
-// request per entry: 0.10 + 0.07 ms at 2^20); staging the output in LDS halved them.
-// Skew: when a whole wave hits one counter (many equal scalars, boolean witnesses) the increment is aggregated into
-// one atomic per wave.
-constexpr int FINE_LOG_MAX = 8;  // fine buckets per coarse bin = 2^fine_log, fine_log = 8 (n <= 2^23) or 7 (n <= 2^24):
-                                // a level-A entry is ONE word, sign | low bucket bits | point index
-
-// atomicAdd(&counter[idx], 1) returning the old value, with the wave-uniform case folded into one atomic
-__device__ __forceinline__ uint32_t lds_count(uint32_t* counter, uint32_t idx) {
-    const uint32_t first = __builtin_amdgcn_readfirstlane(idx);
-    const uint64_t act = __ballot(1);
-    const uint64_t same = __ballot(idx == first);
-    if (same == act) {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-        uint32_t base = 0;
-        if (rank == 0) base = atomicAdd(&counter[first], (uint32_t)__popcll(act));
-        base = __builtin_amdgcn_readfirstlane(base);
-        return base + rank;
-    }
-    return atomicAdd(&counter[idx], 1u);
-}
-
-template <class DIG>
-static __global__ __launch_bounds__(SORT_THREADS) void hist_hi_kernel(const DIG* __restrict__ dig, uint32_t n, uint32_t dstride, int c,
-                                                                      int w_first, int nchunk, uint32_t chunk_len, int fine_log,
-                                                                      uint32_t* __restrict__ hist) {
-    extern __shared__ uint32_t lds[];
-    const uint32_t B = 1u << (c - 1), NB = B >> fine_log;
-    const int wl = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
-    for (uint32_t b = threadIdx.x; b < NB; b += SORT_THREADS) lds[b] = 0;
-    __syncthreads();
-    uint32_t lo = chunk * chunk_len, hi = lo + chunk_len;
-    if (hi > n) hi = n;
-    const DIG* d = dig + (size_t)(w_first + wl) * dstride;
-    // chunk_len is a multiple of 8 and the digit rows are 16-byte aligned: eight digits per lane
-    for (uint32_t i = lo + threadIdx.x * 8; i < hi; i += SORT_THREADS * 8) {
-        uint32_t dg[8];
-        load8_digits<DIG>(d + i, dg);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            int v = (int)dg[k] - (int)B;
-            if (i + k < hi && v != 0) (void)lds_count(lds, ((uint32_t)(v < 0 ? -v : v) - 1) >> fine_log);
-        }
-    }
-    __syncthreads();
-    uint32_t* out = hist + (size_t)blockIdx.x * NB;
-    for (uint32_t b = threadIdx.x; b < NB; b += SORT_THREADS) out[b] = lds[b];
-}
-
-// counts[(set, sub, bin)] -> start offsets in (set, bin, sub) order, in place; bin_start[(set, bin)] (+ the grand
-// total as last entry, also stored at *total_out = bucket_start[n_keys]).  One workgroup; pairs = sets * NB <= 4096.
-// The sub-histograms of a (set, bin) pair are cut into `tpp` contiguous slices, one thread each, with the bin index
-// running fastest over the lanes (coalesced rows of the histogram): a window-range run of a sharded MSM has few pairs and
-// many sub-histograms per pair, and a thread per pair would walk them one dependent load at a time (44 us for two windows).
-static __global__ __launch_bounds__(1024) void bins_scan_kernel(uint32_t* __restrict__ hist, int sets, int subs /* sub-histograms per set */, uint32_t NB,
-                                                                uint32_t* __restrict__ bin_start, uint32_t* __restrict__ total_out) {
-    __shared__ uint32_t tot[4096];
-    __shared__ uint32_t ssum[4096];
-    __shared__ uint32_t sums[1024];
-    const uint32_t pairs = (uint32_t)sets * NB;
-    uint32_t tpp = pairs >= 4096 ? 1u : 4096u / pairs;   // slices per pair (power of two: NB is one, sets need not be)
-    while (tpp & (tpp - 1)) tpp &= tpp - 1;
-    if (tpp > (uint32_t)subs) tpp = 1u << (31 - __clz(subs));
-    const uint32_t slice_len = ((uint32_t)subs + tpp - 1) / tpp;
-    const uint32_t items = pairs * tpp;                    // <= 4096
-    // item = (set, slice, bin), bin fastest
-    for (uint32_t it = threadIdx.x; it < items; it += blockDim.x) {
-        const uint32_t bin = it % NB, sl = (it / NB) % tpp, set = it / (NB * tpp);
-        const uint32_t ch0 = sl * slice_len, ch1 = min((uint32_t)subs, ch0 + slice_len);
-        uint32_t t = 0;
-#pragma unroll 8
-        for (uint32_t ch = ch0; ch < ch1; ++ch) t += hist[((size_t)set * subs + ch) * NB + bin];
-        ssum[it] = t;
-    }
-    __syncthreads();
-    for (uint32_t p = threadIdx.x; p < pairs; p += blockDim.x) {
-        const uint32_t set = p / NB, bin = p % NB;
-        uint32_t t = 0;
-        for (uint32_t sl = 0; sl < tpp; ++sl) t += ssum[(set * tpp + sl) * NB + bin];
-        tot[p] = t;
-    }
-    __syncthreads();
-    {
-        // exclusive scan of tot[0 .. pairs): four consecutive entries per thread, then a Hillis-Steele scan of the 1024 sums
-        uint32_t v[4], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t p = threadIdx.x * 4 + k;
-            v[k] = p < pairs ? tot[p] : 0u;
-            sum += v[k];
-        }
-        sums[threadIdx.x] = sum;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            uint32_t o = (int)threadIdx.x >= d ? sums[threadIdx.x - d] : 0u;
-            __syncthreads();
-            sums[threadIdx.x] += o;
-            __syncthreads();
-        }
-        uint32_t run = sums[threadIdx.x] - sum;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t p = threadIdx.x * 4 + k;
-            if (p < pairs) tot[p] = run;
-            run += v[k];
-        }
-        if (threadIdx.x == 1023) {
-            bin_start[pairs] = sums[1023];
-            *total_out = sums[1023];
-        }
-    }
-    __syncthreads();
-    for (uint32_t p = threadIdx.x; p < pairs; p += blockDim.x) bin_start[p] = tot[p];
-    for (uint32_t it = threadIdx.x; it < items; it += blockDim.x) {
-        const uint32_t bin = it % NB, sl = (it / NB) % tpp, set = it / (NB * tpp);
-        const uint32_t ch0 = sl * slice_len, ch1 = min((uint32_t)subs, ch0 + slice_len);
-        uint32_t run = tot[set * NB + bin];
-        for (uint32_t k = 0; k < sl; ++k) run += ssum[(set * tpp + k) * NB + bin];
-        for (uint32_t ch = ch0; ch < ch1; ++ch) {
-            const size_t idx = ((size_t)set * subs + ch) * NB + bin;
-            uint32_t t = hist[idx];
-            hist[idx] = run;
-            run += t;
-        }
-    }
-}
-
-// The same in three launches for large tables (fixed-base plans: up to 4096 bins x ~250 sub-histograms = 1 M counters, 0.2 ms
-// in one workgroup): a grid of workgroups of 64 bins x 16 slices of the sub-histograms.
-constexpr int BINS_SLICES = 16;
-static __global__ __launch_bounds__(1024) void bins_partial_kernel(const uint32_t* __restrict__ hist, int subs, uint32_t NB, uint32_t pairs,
-                                                                   uint32_t* __restrict__ slice_sums, uint32_t* __restrict__ tot) {
-    __shared__ uint32_t sh[BINS_SLICES][64];
-    const uint32_t lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const uint32_t p = blockIdx.x * 64 + lane;
-    const uint32_t slice_len = ((uint32_t)subs + BINS_SLICES - 1) / BINS_SLICES;
-    uint32_t t = 0;
-    if (p < pairs) {
-        const uint32_t set = p / NB, bin = p % NB;
-        const uint32_t ch0 = sl * slice_len, ch1 = min((uint32_t)subs, ch0 + slice_len);
-#pragma unroll 4
-        for (uint32_t ch = ch0; ch < ch1; ++ch) t += hist[((size_t)set * subs + ch) * NB + bin];
-        slice_sums[(size_t)p * BINS_SLICES + sl] = t;
-    }
-    sh[sl][lane] = t;
-    __syncthreads();
-    if (sl == 0 && p < pairs) {
-        uint32_t a = 0;
-#pragma unroll
-        for (int k = 0; k < BINS_SLICES; ++k) a += sh[k][lane];
-        tot[p] = a;
-    }
-}
-// exclusive scan of tot[0 .. pairs), pairs <= 4096, one workgroup
-static __global__ __launch_bounds__(1024) void bins_scan_tot_kernel(const uint32_t* __restrict__ tot, uint32_t pairs,
-                                                                    uint32_t* __restrict__ bin_start, uint32_t* __restrict__ total_out) {
-    __shared__ uint32_t sums[1024];
-    uint32_t v[4], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t p = threadIdx.x * 4 + k;
-        v[k] = p < pairs ? tot[p] : 0u;
-        sum += v[k];
-    }
-    sums[threadIdx.x] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        uint32_t o = (int)threadIdx.x >= d ? sums[threadIdx.x - d] : 0u;
-        __syncthreads();
-        sums[threadIdx.x] += o;
-        __syncthreads();
-    }
-    uint32_t run = sums[threadIdx.x] - sum;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t p = threadIdx.x * 4 + k;
-        if (p < pairs) bin_start[p] = run;
-        run += v[k];
-    }
-    if (threadIdx.x == 1023) {
-        bin_start[pairs] = sums[1023];
-        *total_out = sums[1023];
-    }
-}
-static __global__ __launch_bounds__(1024) void bins_prefix_kernel(uint32_t* __restrict__ hist, int subs, uint32_t NB, uint32_t pairs,
-                                                                  const uint32_t* __restrict__ slice_sums, const uint32_t* __restrict__ bin_start) {
-    const uint32_t lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const uint32_t p = blockIdx.x * 64 + lane;
-    if (p >= pairs) return;
-    const uint32_t slice_len = ((uint32_t)subs + BINS_SLICES - 1) / BINS_SLICES;
-    const uint32_t set = p / NB, bin = p % NB;
-    uint32_t run = bin_start[p];
-    for (uint32_t k = 0; k < sl; ++k) run += slice_sums[(size_t)p * BINS_SLICES + k];
-    const uint32_t ch0 = sl * slice_len, ch1 = min((uint32_t)subs, ch0 + slice_len);
-    for (uint32_t ch = ch0; ch < ch1; ++ch) {
-        const size_t idx = ((size_t)set * subs + ch) * NB + bin;
-        const uint32_t t = hist[idx];
-        hist[idx] = run;
-        run += t;
-    }
-}
-
-// Level A with the output staged through LDS: the chunk is processed in tiles of 8192 entries (one 16-byte digit
-// load per lane); a tile is counted and ranked per bin in LDS, the bin counts are scanned (every wave its share of the
-// bins, then the 16 wave totals), the entries are placed bin-sorted into an LDS buffer and written out run by run, so
-// that a run is one coalesced store instead of one four-byte request per entry -- the direct form is bound by the L2
-// request rate.  Dynamic LDS: buf[8192] u32 | tcnt, toff, gcur [NBP] u32 | slot_bin[8192] u16, NBP = bins padded to 128.
-constexpr uint32_t SCATTER_TILE = SORT_THREADS * 8;
-
-template <class DIG>
-static __global__ __launch_bounds__(SORT_THREADS) void scatter_hi_staged_kernel(const DIG* __restrict__ dig, uint32_t n, uint32_t dstride, int c,
-                                                                                int w_first, int nchunk, uint32_t chunk_len, int fine_log,
-                                                                                int shared_buckets, uint32_t table_stride, int table_w0,
-                                                                                const uint32_t* __restrict__ offsets,
-                                                                                uint32_t* __restrict__ tmp, uint8_t* __restrict__ tmp_fine) {
-    // tmp_fine != nullptr: the reference alone fills the 31 bits below the sign (fixed-base keys above 2^20 points with
-    // 20-bit windows: 13 x 2^22 table rows), and the fine bucket bits travel in a byte array beside the entries
-    extern __shared__ uint32_t lds[];
-    __shared__ uint32_t wave_tot[SORT_THREADS / 64];
-    const bool split = tmp_fine != nullptr;
-    const uint32_t B = 1u << (c - 1), NB = B >> fine_log;
-    const uint32_t NBP = (NB + 127) & ~127u;          // multiple of 2 bins x 64 lanes
-    const uint32_t per_wave = NBP / (SORT_THREADS / 64);  // bins scanned by one wave: <= 256 (NBP <= 4096)
-    uint32_t* buf = lds;
-    uint32_t* tcnt = lds + SCATTER_TILE;
-    uint32_t* toff = tcnt + NBP;
-    uint32_t* gcur = toff + NBP;
-    uint16_t* slot_bin = reinterpret_cast<uint16_t*>(gcur + NBP);
-    uint8_t* slot_fine = reinterpret_cast<uint8_t*>(slot_bin + SCATTER_TILE);   // used when split
-    const int index_bits = 31 - fine_log;
-    const int wl = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
-    const uint32_t* off = offsets + (size_t)blockIdx.x * NB;
-    for (uint32_t b = threadIdx.x; b < NBP; b += SORT_THREADS) {
-        gcur[b] = b < NB ? off[b] : 0u;
-        tcnt[b] = 0;
-    }
-    __syncthreads();
-    uint32_t lo = chunk * chunk_len, hi = lo + chunk_len;
-    if (hi > n) hi = n;
-    const DIG* d = dig + (size_t)(w_first + wl) * dstride;
-    const uint32_t ref_base = shared_buckets ? (uint32_t)(w_first + wl - table_w0) * table_stride : 0;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (uint32_t base = lo; base < hi; base += SCATTER_TILE) {
-        const uint32_t i = base + threadIdx.x * 8;
-        uint32_t val[8], rank[8];
-        uint16_t bin[8];
-        uint8_t fine[8];
-        uint32_t dg[8] = {B, B, B, B, B, B, B, B};
-        if (i < hi) load8_digits<DIG>(d + i, dg);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            int v = (int)dg[k] - (int)B;
-            bin[k] = 0xFFFF;
-            if (i + k < hi && v != 0) {
-                const uint32_t b = (uint32_t)(v < 0 ? -v : v) - 1;
-                bin[k] = (uint16_t)(b >> fine_log);
-                fine[k] = (uint8_t)(b & ((1u << fine_log) - 1));
-                val[k] = (v < 0 ? 0x80000000u : 0u) | (split ? 0u : ((uint32_t)fine[k] << index_bits)) | (ref_base + i + k);
-                rank[k] = lds_count(tcnt, bin[k]);
-            }
-        }
-        __syncthreads();
-        // exclusive scan of the tile's bin counts: wave w scans bins [w per_wave, (w+1) per_wave), per_wave / 64 = up to
-        // four consecutive bins per lane (NBP <= 4096 coarse bins)
-        const uint32_t bpl = (per_wave + 63) / 64;
-        uint32_t cb[4] = {0, 0, 0, 0}, incl = 0;
-        {
-            const uint32_t b0 = wave * per_wave + lane * bpl;
-#pragma unroll
-            for (uint32_t t = 0; t < 4; ++t)
-                if (t < bpl && lane * bpl + t < per_wave) cb[t] = tcnt[b0 + t];
-            incl = cb[0] + cb[1] + cb[2] + cb[3];
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                uint32_t o = __shfl_up(incl, dd, 64);
-                if ((int)lane >= dd) incl += o;
-            }
-            if (lane == 63) wave_tot[wave] = incl;
-        }
-        __syncthreads();
-        {
-            uint32_t run = 0;
-            for (uint32_t w2 = 0; w2 < wave; ++w2) run += wave_tot[w2];
-            run += incl - (cb[0] + cb[1] + cb[2] + cb[3]);
-            const uint32_t b0 = wave * per_wave + lane * bpl;
-#pragma unroll
-            for (uint32_t t = 0; t < 4; ++t)
-                if (t < bpl && lane * bpl + t < per_wave) {
-                    toff[b0 + t] = run;
-                    run += cb[t];
-                }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (bin[k] != 0xFFFF) {
-                const uint32_t slot = toff[bin[k]] + rank[k];
-                buf[slot] = val[k];
-                slot_bin[slot] = bin[k];
-                if (split) slot_fine[slot] = fine[k];
-            }
-        }
-        __syncthreads();
-        const uint32_t count = toff[NBP - 1] + tcnt[NBP - 1];  // entries of this tile
-        for (uint32_t sidx = threadIdx.x; sidx < count; sidx += SORT_THREADS) {
-            const uint32_t b = slot_bin[sidx];
-            const uint32_t pos = gcur[b] + (sidx - toff[b]);
-            tmp[pos] = buf[sidx];
-            if (split) tmp_fine[pos] = slot_fine[sidx];
-        }
-        __syncthreads();
-        for (uint32_t b = threadIdx.x; b < NBP; b += SORT_THREADS) {
-            gcur[b] += tcnt[b];
-            tcnt[b] = 0;
-        }
-        __syncthreads();
-    }
-}
-
-constexpr int SORT_LO_THREADS = 1024;
-
-static __global__ __launch_bounds__(SORT_LO_THREADS) void sort_lo_kernel(const uint32_t* __restrict__ bin_start, const uint32_t* __restrict__ tmp, const uint8_t* __restrict__ tmp_fine,
-                                                                         uint32_t B, int fine_log, uint32_t stage_cap,
-                                                                         uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ sorted) {
-    const bool split = tmp_fine != nullptr;  // fine bucket bits beside the entries (see scatter_hi_staged_kernel)
-    constexpr uint32_t FINE = 1u << FINE_LOG_MAX;  // counters; the upper ones stay zero when fine_log < FINE_LOG_MAX
-    __shared__ uint32_t cnt[FINE];
-    extern __shared__ uint32_t stage[];  // stage_cap entries
-    const uint32_t NB = B >> fine_log;
-    const int index_bits = 31 - fine_log;
-    const uint32_t fine_mask = (1u << fine_log) - 1;
-    const uint32_t wl = blockIdx.x / NB, bin = blockIdx.x % NB;
-    const uint32_t s0 = bin_start[blockIdx.x], s1 = bin_start[blockIdx.x + 1];
-    for (uint32_t f = threadIdx.x; f < FINE; f += SORT_LO_THREADS) cnt[f] = 0;
-    __syncthreads();
-    for (uint32_t e = s0 + threadIdx.x; e < s1; e += SORT_LO_THREADS) (void)lds_count(cnt, split ? (uint32_t)tmp_fine[e] : (tmp[e] >> index_bits) & fine_mask);
-    __syncthreads();
-    if (threadIdx.x < 64) {  // exclusive scan of the 256 counts by one wave: 4 per lane + a shuffle scan
-        uint32_t v[4], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            v[k] = cnt[threadIdx.x * 4 + k];
-            sum += v[k];
-        }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t o = __shfl_up(incl, d, 64);
-            if ((int)threadIdx.x >= d) incl += o;
-        }
-        uint32_t run = incl - sum;  // offsets relative to the bin's slice
-        uint32_t* bs = bucket_start + (size_t)wl * B + ((size_t)bin << fine_log);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t f = threadIdx.x * 4 + k;
-            cnt[f] = run;
-            if (f <= fine_mask) bs[f] = s0 + run;
-            run += v[k];
-        }
-    }
-    __syncthreads();
-    // The placing pass scatters inside the bin's own slice: done in LDS when the slice fits (the typical n / 128
-    // entries), so that HBM/L2 see 16-byte-per-lane coalesced stores instead of one 4-byte request per entry -- the
-    // scattered form is bound by the L2 request rate, not by bytes.
-    const bool staged = s1 - s0 <= stage_cap;
-    for (uint32_t e = s0 + threadIdx.x; e < s1; e += SORT_LO_THREADS) {
-        const uint32_t t = tmp[e];
-        const uint32_t pos = lds_count(cnt, split ? (uint32_t)tmp_fine[e] : (t >> index_bits) & fine_mask);
-        const uint32_t ref = split ? t : (t & 0x80000000u) | (t & ((1u << index_bits) - 1));
-        if (staged) stage[pos] = ref;
-        else sorted[s0 + pos] = ref;
-    }
-    if (staged) {
-        __syncthreads();
-        for (uint32_t e = threadIdx.x; e < s1 - s0; e += SORT_LO_THREADS) sorted[s0 + e] = stage[e];
-    }
-}
-
-// ---- 2'/4'. bucket-range partition (general mode) -----------------------------------------------------
-// One workgroup per (window, bucket range): it scans ALL digits of its window (2 B each, L2-resident, read
-// 16 B per lane) and keeps only the entries whose bucket falls in its range.  Compared with the chunked
-// scheme above this reads the digits `n_range` times, but every output line is written by ONE workgroup, so
-// the 4-byte scattered stores are merged in its L2 instead of being written back as 8x amplified partial
-// lines from 16 different XCD caches, and no per-chunk histogram / prefix pass is needed.
-static __global__ __launch_bounds__(SORT_THREADS) void hist_range_kernel(const uint16_t* __restrict__ dig, uint32_t n, uint32_t dstride, int c,
-                                                                         int w_first, int range_log,
-                                                                         uint32_t* __restrict__ total) {
-    extern __shared__ uint32_t lds[];
-    const uint32_t B = 1u << (c - 1);
-    const uint32_t n_range = B >> range_log;
-    const uint32_t wl = blockIdx.x / n_range, r = blockIdx.x % n_range;
-    const uint32_t range = 1u << range_log;
-    const uint32_t lo_bucket = r << range_log;
-    for (uint32_t b = threadIdx.x; b < range; b += SORT_THREADS) lds[b] = 0;
-    __syncthreads();
-    const uint16_t* d = dig + (size_t)(w_first + wl) * dstride;
-    const uint32_t n8 = n & ~7u;
-    for (uint32_t i = threadIdx.x * 8; i < n8; i += SORT_THREADS * 8) {
-        uint4 pk = *reinterpret_cast<const uint4*>(d + i);
-        const uint32_t wds[4] = {pk.x, pk.y, pk.z, pk.w};
-        // bucket index relative to this range: rel < range <=> the entry is ours (v == 0 wraps to a huge value)
-        uint32_t rel[8];
-        uint32_t any = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            int v = (int)((wds[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu) - (int)B;
-            rel[k] = (uint32_t)(v < 0 ? -v : v) - 1u - lo_bucket;
-            any |= (rel[k] < range) ? 1u : 0u;
-        }
-        if (any) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (rel[k] < range) atomicAdd(&lds[rel[k]], 1u);
-        }
-    }
-    for (uint32_t i = n8 + threadIdx.x; i < n; i += SORT_THREADS) {
-        int v = (int)d[i] - (int)B;
-        uint32_t rel = (uint32_t)(v < 0 ? -v : v) - 1u - lo_bucket;
-        if (rel < range) atomicAdd(&lds[rel], 1u);
-    }
-    __syncthreads();
-    uint32_t* out = total + (size_t)wl * B + (size_t)r * range;
-    for (uint32_t b = threadIdx.x; b < range; b += SORT_THREADS) out[b] = lds[b];
-}
-
-static __global__ __launch_bounds__(SORT_THREADS) void scatter_range_kernel(const uint16_t* __restrict__ dig, uint32_t n, uint32_t dstride, int c,
-                                                                            int w_first, int range_log,
-                                                                            const uint32_t* __restrict__ bucket_start,
-                                                                            uint32_t* __restrict__ sorted) {
-    extern __shared__ uint32_t lds[];
-    const uint32_t B = 1u << (c - 1);
-    const uint32_t n_range = B >> range_log;
-    const uint32_t wl = blockIdx.x / n_range, r = blockIdx.x % n_range;
-    const uint32_t range = 1u << range_log;
-    const uint32_t lo_bucket = r << range_log;
-    const uint32_t* start = bucket_start + (size_t)wl * B + (size_t)r * range;
-    for (uint32_t b = threadIdx.x; b < range; b += SORT_THREADS) lds[b] = start[b];
-    __syncthreads();
-    const uint16_t* d = dig + (size_t)(w_first + wl) * dstride;
-    const uint32_t n8 = n & ~7u;
-    for (uint32_t i = threadIdx.x * 8; i < n8; i += SORT_THREADS * 8) {
-        uint4 pk = *reinterpret_cast<const uint4*>(d + i);
-        const uint32_t wds[4] = {pk.x, pk.y, pk.z, pk.w};
-        uint32_t rel[8];
-        uint32_t any = 0, negs = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            int v = (int)((wds[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu) - (int)B;
-            rel[k] = (uint32_t)(v < 0 ? -v : v) - 1u - lo_bucket;
-            negs |= (v < 0 ? 1u : 0u) << k;
-            any |= (rel[k] < range) ? 1u : 0u;
-        }
-        if (any) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (rel[k] < range) {
-                    uint32_t pos = atomicAdd(&lds[rel[k]], 1u);
-                    sorted[pos] = (i + k) | (((negs >> k) & 1u) << 31);
-                }
-        }
-    }
-    for (uint32_t i = n8 + threadIdx.x; i < n; i += SORT_THREADS) {
-        int v = (int)d[i] - (int)B;
-        uint32_t rel = (uint32_t)(v < 0 ? -v : v) - 1u - lo_bucket;
-        if (rel < range) {
-            uint32_t pos = atomicAdd(&lds[rel], 1u);
-            sorted[pos] = i | (v < 0 ? 0x80000000u : 0u);
-        }
-    }
-}
-
-#endif  // ZK_PART == 0
-
-// ---- 5. accumulate (dominant kernel) ----------------------------------------------------------------
-
-// where lane t's run of bucket `key` goes: a bucket that lies within ONE segment has one run, which is the bucket sum itself
-// and is written straight to the bucket array (combine_kernel skips such buckets); otherwise the run's slot in `partials`
-template <class F>
-__device__ __forceinline__ uint32_t* run_slot(uint32_t* partials, uint32_t* buckets, const uint32_t* run_start, const uint32_t* bucket_start,
-                                              uint32_t key, uint32_t t, uint32_t seg_len) {
-    constexpr int XW = 4 * F::LIMBS;
-    const uint32_t r0 = run_start[key];
-    if (run_start[key + 1] - r0 == 1) return buckets + (size_t)key * XW;
-    return partials + (size_t)(r0 + t - bucket_start[key] / seg_len) * XW;
-}
-
-template <class G>
-__global__ __launch_bounds__(256) void accumulate_kernel(const uint32_t* __restrict__ bases,
-                                                         const uint32_t* __restrict__ sorted,
-                                                         const uint32_t* __restrict__ bucket_start,
-                                                         const uint32_t* __restrict__ run_start, uint32_t n_keys,
-                                                         uint32_t seg_len, uint32_t* __restrict__ partials,
-                                                         uint32_t* __restrict__ buckets) {
-    typedef typename G::F F;
-    constexpr int AW = 2 * F::LIMBS;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t total = bucket_start[n_keys];
-    const uint32_t begin = t * seg_len;
-    if (begin >= total) return;
-    uint32_t end = begin + seg_len;
-    if (end > total) end = total;
-    // bucket of the first entry: largest key with bucket_start[key] <= begin (its end is > begin)
-    uint32_t lo = 0, hi = n_keys;
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (bucket_start[mid] <= begin) lo = mid; else hi = mid;
-    }
-    uint32_t key = lo;
-    uint32_t next = bucket_start[key + 1];
-    XYZZ<F> acc = xyzz_inf<F>();
-    for (uint32_t e = begin; e < end; ++e) {
-        if (e == next) {
-            // the bucket ends inside this segment: flush its run, move to the next non-empty bucket
-            store_xyzz<F>(run_slot<F>(partials, buckets, run_start, bucket_start, key, t, seg_len), acc);
-            acc = xyzz_inf<F>();
-            do {
-                ++key;
-                next = bucket_start[key + 1];
-            } while (next <= e);
-        }
-        uint32_t ref = sorted[e];
-        const uint32_t* src = bases + (size_t)(ref & 0x7FFFFFFFu) * AW;
-        xyzz_add_affine_mem<F>(acc, src, (ref >> 31) != 0);
-    }
-    store_xyzz<F>(run_slot<F>(partials, buckets, run_start, bucket_start, key, t, seg_len), acc);
-}
-
-// ---- 6. combine ---------------------------------------------------------------------------------
-// bucket = sum of its runs, three tiers in ONE launch (every dependent launch costs ~5 us of latency, and the two upper
-// tiers are empty unless the scalars are skewed).  A point is held by a lane pair (pair.cuh) in all tiers.
-//   blocks [0, small_blocks)                 one pair per bucket with 2 .. COMBINE_SMALL_MAX runs
-//   blocks [small_blocks, + COMBINE_WAVE_BLOCKS)  one wave (32 pairs) per listed bucket, <= COMBINE_WAVE_MAX runs
-//   the rest                                 one workgroup (128 pairs) per listed bucket
-constexpr int COMBINE_THREADS = 256;
-constexpr uint32_t COMBINE_WAVE_BLOCKS = 128, COMBINE_BIG_BLOCKS = 64;
-
-template <class G>
-__global__ __launch_bounds__(COMBINE_THREADS) void combine_kernel(const uint32_t* __restrict__ partials,
-                                                                  const uint32_t* __restrict__ run_start, uint32_t n_keys,
-                                                                  uint32_t small_blocks, const uint32_t* __restrict__ big_list,
-                                                                  const uint32_t* __restrict__ big_count,
-                                                                  uint32_t* __restrict__ buckets) {
-    typedef typename G::F F;
-    constexpr int XW = 4 * F::LIMBS;
-    constexpr int HW = HalfRegs<F>::COUNT;
-    __shared__ uint32_t sh[COMBINE_THREADS * HW];
-    const bool odd = (threadIdx.x & 1) != 0;
-    if (blockIdx.x < small_blocks) {
-        const uint32_t key = (blockIdx.x * COMBINE_THREADS + threadIdx.x) >> 1;
-        if (key >= n_keys) return;
-        const uint32_t s0 = run_start[key], s1 = run_start[key + 1];
-        // a single run: accumulate_kernel wrote the bucket itself; no run: it is never read... but the reduction reads
-        // every bucket, so an empty one is set to infinity here
-        if (s1 - s0 == 1 || s1 - s0 > COMBINE_SMALL_MAX) return;
-        HalfPt<F> acc = half_inf<F>();
-        if (s1 > s0) {
-            acc = half_load<F>(partials + (size_t)s0 * XW, odd);
-            // the next run is loaded before the addition of the current one: the chain is additions only, not
-            // load-then-add round trips
-            HalfPt<F> cur = s0 + 1 < s1 ? half_load<F>(partials + (size_t)(s0 + 1) * XW, odd) : half_inf<F>();
-            for (uint32_t r = s0 + 1; r < s1; ++r) {
-                HalfPt<F> nxt = r + 1 < s1 ? half_load<F>(partials + (size_t)(r + 1) * XW, odd) : half_inf<F>();
-                acc = pair_add<F>(acc, cur, odd);
-                cur = nxt;
-            }
-        }
-        half_store<F>(buckets + (size_t)key * XW, odd, acc);
-    } else if (blockIdx.x < small_blocks + COMBINE_WAVE_BLOCKS) {
-        const uint32_t count = big_count[0];
-        const uint32_t lane = threadIdx.x & 63, pair = lane >> 1;
-        const uint32_t wave = ((blockIdx.x - small_blocks) * COMBINE_THREADS + threadIdx.x) >> 6;
-        const uint32_t n_waves = (COMBINE_WAVE_BLOCKS * COMBINE_THREADS) >> 6;
-        for (uint32_t b = wave; b < count; b += n_waves) {
-            const uint32_t key = big_list[b];
-            const uint32_t s0 = run_start[key], s1 = run_start[key + 1];
-            HalfPt<F> v = half_inf<F>();
-            for (uint32_t r = s0 + pair; r < s1; r += 32) v = pair_add<F>(v, half_load<F>(partials + (size_t)r * XW, odd), odd);
-            for (int m = 32; m >= 2; m >>= 1) v = pair_add<F>(v, half_shfl_xor<F>(v, m), odd);
-            if (lane < 2) half_store<F>(buckets + (size_t)key * XW, odd, v);
-        }
-    } else {
-        const uint32_t count = big_count[1];
-        const uint32_t j = threadIdx.x, pair = j >> 1;
-        for (uint32_t b = blockIdx.x - small_blocks - COMBINE_WAVE_BLOCKS; b < count; b += COMBINE_BIG_BLOCKS) {
-            const uint32_t key = big_list[n_keys - 1 - b];
-            const uint32_t s0 = run_start[key], s1 = run_start[key + 1];
-            HalfPt<F> v = half_inf<F>();
-            for (uint32_t r = s0 + pair; r < s1; r += COMBINE_THREADS / 2) v = pair_add<F>(v, half_load<F>(partials + (size_t)r * XW, odd), odd);
-            for (uint32_t off = COMBINE_THREADS / 4; off >= 1; off >>= 1) {  // tree over the 128 pairs
-                half_lds_put<F>(sh, COMBINE_THREADS, j, v);
-                __syncthreads();
-                if (pair < off) v = pair_add<F>(v, half_lds_get<F>(sh, COMBINE_THREADS, j + 2 * off), odd);
-                __syncthreads();
-            }
-            if (j < 2) half_store<F>(buckets + (size_t)key * XW, odd, v);
-        }
-    }
-}
-
-// ---- 7. bucket reduction ----------------------------------------------------------------------------
-// Both kernels hold a point as a lane pair (pair.cuh): an addition is seven multiplications deep instead of
-// fourteen and a half, which is what these latency-bound stages are made of.
-
-// Two strided sums in one launch (rows and columns run side by side):
-//   out[o] = sum_{j < count} in[(o / per_group) * group_stride + (o % per_group) * outer + j * inner]
-// lpo lanes = lpo / 2 pairs per output element; the pairs stride over j, then a shuffle tree over the pairs.
-struct SumJob {
-    uint32_t n_out, per_group, group_stride, outer, inner, count;
-    uint32_t out_offset;  // in points, into the shared output array
-    uint32_t split = 1, outer2 = 0;  // the index x inside a group is taken apart: (x / split) * outer + (x % split) * outer2
-    uint32_t in_offset = 0;          // in points, into the input array
-};
-
-template <class G>
-__global__ __launch_bounds__(256) void strided_sum_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                          SumJob j0, SumJob j1, uint32_t lpo) {
-    typedef typename G::F F;
-    constexpr int XW = 4 * F::LIMBS;
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t o = gid / lpo;
-    const uint32_t sub = gid % lpo;
-    const bool odd = (sub & 1) != 0;
-    const uint32_t pair = sub >> 1, n_pairs = lpo >> 1;
-    SumJob job = j0;
-    if (o >= j0.n_out) {
-        o -= j0.n_out;
-        job = j1;
-    }
-    const bool live = o < job.n_out;  // dead groups still take part in the shuffles
-    const uint32_t x = live ? o % job.per_group : 0;
-    size_t base = live ? (size_t)job.in_offset + (size_t)(o / job.per_group) * job.group_stride + (size_t)(x / job.split) * job.outer + (size_t)(x % job.split) * job.outer2 : 0;
-    HalfPt<F> acc = half_inf<F>();
-    if (live && pair < job.count) {
-        // the next point is requested before the current addition starts: a step of the chain is an addition, not a
-        // load followed by an addition
-        HalfPt<F> cur = half_load<F>(in + (base + (size_t)pair * job.inner) * XW, odd);
-        for (uint32_t j = pair; j < job.count; j += n_pairs) {
-            const uint32_t jn = j + n_pairs < job.count ? j + n_pairs : j;
-            HalfPt<F> nxt = half_load<F>(in + (base + (size_t)jn * job.inner) * XW, odd);
-            acc = pair_add<F>(acc, cur, odd);
-            cur = nxt;
-        }
-    }
-    for (uint32_t m = lpo >> 1; m >= 2; m >>= 1) {
-        HalfPt<F> other = half_shfl_xor<F>(acc, (int)m);
-        acc = pair_add<F>(acc, other, odd);
-    }
-    if (live && sub < 2) half_store<F>(out + ((size_t)job.out_offset + o) * XW, odd, acc);
-}
-
-// S = sum_j j * X_j and T = sum_j X_j over BLOCKS of at most WS_BLOCK points of the input arrays, one workgroup per
-// block, two lanes per point (so a workgroup is four waves: one per SIMD of its CU), via an inclusive suffix scan
-// (log m steps) followed by a tree sum of the suffixes 1..m-1.  n0 arrays of m0 points from in0, then arrays of m1
-// points from in1; block k of an array covers its points [k WS_BLOCK, ..) with LOCAL weights 0, 1, ..: the host tail adds
-// k WS_BLOCK T_k along its Horner chain, where those doublings cost nothing extra.  out: (S, T) per block, arrays of
-// in0 first.  Dynamic LDS: HalfRegs<F>::COUNT words per lane, word-major.
-constexpr int WS_BLOCK = 128;
-constexpr int WS_BLOCK_LOG = 7;
-constexpr int HS_THREADS = 2 * WS_BLOCK;
-template <class G>
-__global__ __launch_bounds__(HS_THREADS) void weighted_sum_kernel(const uint32_t* __restrict__ in0, uint32_t m0, uint32_t n0,
-                                                                  const uint32_t* __restrict__ in1, uint32_t m1,
-                                                                  uint32_t* __restrict__ out) {
-    typedef typename G::F F;
-    constexpr int XW = 4 * F::LIMBS;
-    extern __shared__ uint32_t sh[];
-    const uint32_t tid = threadIdx.x, pj = tid >> 1;
-    const bool odd = (tid & 1) != 0;
-    const uint32_t bpa0 = (m0 + WS_BLOCK - 1) / WS_BLOCK, bpa1 = (m1 + WS_BLOCK - 1) / WS_BLOCK;
-    const bool first = blockIdx.x < n0 * bpa0;
-    const uint32_t rel = first ? blockIdx.x : blockIdx.x - n0 * bpa0;
-    const uint32_t bpa = first ? bpa0 : bpa1, ma = first ? m0 : m1;
-    const uint32_t arr_i = rel / bpa, blk = rel % bpa;
-    const uint32_t m = min((uint32_t)WS_BLOCK, ma - blk * WS_BLOCK);
-    const uint32_t* arr = (first ? in0 : in1) + ((size_t)arr_i * ma + (size_t)blk * WS_BLOCK) * XW;
-    HalfPt<F> v = pj < m ? half_load<F>(arr + (size_t)pj * XW, odd) : half_inf<F>();
-    for (uint32_t off = 1; off < m; off <<= 1) {
-        half_lds_put<F>(sh, HS_THREADS, tid, v);
-        __syncthreads();
-        if (pj + off < m) {
-            HalfPt<F> o = half_lds_get<F>(sh, HS_THREADS, tid + 2 * off);
-            v = pair_add<F>(v, o, odd);
-        }
-        __syncthreads();
-    }
-    // v = suffix sum s_j
-    if (pj == 0) half_store<F>(out + ((size_t)blockIdx.x * 2 + 1) * XW, odd, v);  // T = s_0
-    if (pj == 0 || pj >= m) v = half_inf<F>();
-    uint32_t top = 1;
-    while (top < m) top <<= 1;
-    for (uint32_t off = top / 2; off >= 1; off >>= 1) {
-        half_lds_put<F>(sh, HS_THREADS, tid, v);
-        __syncthreads();
-        if (pj < off) {
-            HalfPt<F> o = half_lds_get<F>(sh, HS_THREADS, tid + 2 * off);
-            v = pair_add<F>(v, o, odd);
-        }
-        __syncthreads();
-    }
-    if (pj == 0) half_store<F>(out + (size_t)blockIdx.x * 2 * XW, odd, v);  // S
-}
-
-// ---- bases: canonical -> Montgomery; batch scalar multiplication -------------------------------------
-
-// glv != 0: rows 2i = P_i and 2i + 1 = phi(P_i) = (beta x, y)
-template <class G>
-__global__ void bases_to_mont_kernel(const uint32_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ out, int glv) {
-    typedef typename G::F F;
-    constexpr int AW = 2 * F::LIMBS;
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t w[AW];
-    load_words<AW>(w, in + i * AW);
-    Affine<F> p;
-    p.x = F::from_canonical(w);
-    p.y = F::from_canonical(w + F::LIMBS);
-    if constexpr (GlvOf<G>::OK) {
-        if (glv) {
-            store_affine<F>(out + 2 * i * AW, p);
-            p.x = F::mul(p.x, F::from_canonical(GlvOf<G>::P::BETA));
-            store_affine<F>(out + (2 * i + 1) * AW, p);
-            return;
-        }
-    }
-    store_affine<F>(out + i * AW, p);
-}
+namespace zkmi {
 
 #if defined(ZK_GROUP) && (!defined(ZK_PART) || ZK_PART == 0)
 // the plan's translation unit does not instantiate the heavy kernels (see msm_group.hip)
@@ -1364,7 +212,7 @@ struct MsmPlan : MsmPlanBase {
     // `share` != nullptr: a clone -- same bases (and fixed-base table), own workspace and stream
     int init(uint64_t n_points, const void* bases, int bases_on_device, int flags, int window_bits, int win_first, int win_count,
              const MsmPlan* share = nullptr) {
-        static const bool trace = getenv("ZKMI_TRACE_INIT") != nullptr;
+        const bool trace = opt.trace_init;
         auto t_prev = std::chrono::steady_clock::now();
         auto mark = [&](const char* what) {
             if (!trace) return;
@@ -1373,6 +221,7 @@ struct MsmPlan : MsmPlanBase {
             t_prev = now;
         };
         create_flags = flags;
+        seg_lanes_at_init = opt.segment_lanes ? opt.segment_lanes : SEG_TARGET_LANES;
         pre = (flags & ZK_MSM_PRECOMPUTE) != 0;
         if (n_points == 0 || n_points > (1ull << 26)) return fail(ZK_ERR_ARG, "MSM size must be in [1, 2^26]");
         const MsmLayout lay = msm_layout(FrP::BITS, GlvOf<G>::OK, n_points, flags, window_bits, win_count <= 0);
@@ -1399,8 +248,7 @@ struct MsmPlan : MsmPlanBase {
         bpc = (C + WS_BLOCK - 1) / WS_BLOCK;
         // bucket ranges (general mode, small inputs): about 256 sort workgroups in total, at least 64 buckets each
         {
-            uint32_t wgs = 256u;
-            if (const char* e = getenv("ZKMI_SORT_WGS")) wgs = (uint32_t)atoi(e);  // tuning knob
+            const uint32_t wgs = opt.sort_workgroups;
             uint32_t want = std::max<uint32_t>(1u, wgs / (uint32_t)std::max(1, pw_count));
             uint32_t per = std::max<uint32_t>(64u, B / want);
             if (per > B) per = B;
@@ -1451,7 +299,7 @@ struct MsmPlan : MsmPlanBase {
             const uint64_t keys = max_sets * B;
             // a window-range run picks its own (shorter) segments: at most SEG_TARGET_LANES of them, or entries / 8
             const uint32_t seg_full = pick_seg_len(entries);
-            const uint64_t max_segs = std::max<uint64_t>(entries / seg_full, std::min<uint64_t>(entries / 8, SEG_TARGET_LANES)) + keys + 8;
+            const uint64_t max_segs = std::max<uint64_t>(entries / seg_full, std::min<uint64_t>(entries / 8, seg_lanes_at_init)) + keys + 8;
             // windows x chunks <= max(256, windows) sub-histograms: of all B buckets (one-level sort) or of the coarse bins only
             ZK_ALLOC(&ws.hist, (size_t)std::max<uint64_t>(256, pw_count) * (wide ? (B >> fine_log_for(n)) : B) * 4);
             ZK_ALLOC(&ws.total, keys * 4);
@@ -1525,7 +373,7 @@ struct MsmPlan : MsmPlanBase {
             const int f = c - 13;  // 4096 coarse bins; the fine bits move out of the entry when the reference needs the room
             return refs <= 0x7FFFFFFFull ? f : 0;
         }
-        static const int f_env = getenv("ZKMI_FINE_LOG") ? atoi(getenv("ZKMI_FINE_LOG")) : 0;  // tuning knob (general mode)
+        const int f_env = opt.fine_log;  // tuning knob (general mode)
         if (f_env && !pre && refs <= (1ull << (31 - f_env)) && c - 1 >= f_env + 2 && sets * (B >> f_env) <= 4096) return f_env;
         const int f_hi = pre ? 5 : FINE_LOG_MAX, f_lo = pre ? 4 : FINE_LOG_MAX - 1;
         // general mode: the widest bins that still hold about 8192 entries each (one level-B workgroup sorts a bin in LDS;
@@ -1552,15 +400,14 @@ struct MsmPlan : MsmPlanBase {
     }
 
     bool two_level_ok() const {
-        static const bool off = getenv("ZKMI_NO_TWO_LEVEL") != nullptr;
-        return !off && fine_log_for(n) > 0;
+        return opt.two_level_sort && fine_log_for(n) > 0;
     }
 
     // Segment length for a run over `entries` sorted entries: aim at >= 4 waves per SIMD worth of lanes (a window-range
     // run of a sharded MSM has far fewer entries than the plan's full set; with the plan-wide length its lanes would
     // be too few and each would walk 64 additions at lone-wave speed).
     uint32_t pick_seg_len(uint64_t entries) const {
-        static const uint64_t target = getenv("ZKMI_SEG_LANES") ? (uint64_t)atoll(getenv("ZKMI_SEG_LANES")) : SEG_TARGET_LANES;
+        const uint64_t target = opt.segment_lanes ? opt.segment_lanes : SEG_TARGET_LANES;
         uint64_t sl = (entries + target - 1) / target;
         if (sl < 8) sl = 8;
         if (sl > 64) sl = 64;
@@ -1574,36 +421,22 @@ struct MsmPlan : MsmPlanBase {
         return (uint32_t)sl;
     }
 
-    // stages 2..7 + D2H for the windows [ws.w_first, ws.w_first + ws.w_count) on stream st
-    // `borrowed`: the digits and the sort of another plan's run over the same scalars (enqueue_shared); stages 1-4 are skipped
-    // phase: 0 = everything, 1 = up to the sorted entry list only, 2 = from the accumulate kernel on (after phase 1).
-    // gate: waited for right before the accumulate kernel (another plan's accumulate has finished), so that the
-    // accumulate kernels of several plans run one after the other while their sorts and reductions overlap.
-    int run_stages(uint32_t m, uint32_t dstride, hipStream_t st, const SortExport* borrowed = nullptr, int phase = 0, hipEvent_t gate = nullptr) {
+    // ---- the stages of one run, for the windows [ws.w_first, ws.w_first + ws.w_count) on stream st -------------------------
+
+    // stages 2-4: histogram, scans, scatter -> ws.sorted / ws.bstart / ws.sstart (+ the lists of buckets with many runs)
+    int stage_sort(uint32_t m, uint32_t dstride, uint32_t seg_len, hipStream_t st) {
         Work& l = ws;
         const int w_first = l.w_first, w_count = l.w_count;
-        const uint32_t groups = l.groups;
-        const uint32_t n_keys = groups * B;
+        const uint32_t n_keys = l.groups * B;
         const int nchunk = chunks_for(w_count, m);  // this run's windows fill the chip
-        const uint32_t seg_len = borrowed ? borrowed->seg_len : pick_seg_len((uint64_t)w_count * m);
-        l.seg_len = seg_len;
         const uint32_t ch_len = (m + nchunk - 1) / nchunk;
-        if (phase != 2) ZK_HIP(hipEventRecord(l.ev_begin, st));
-        const uint32_t *p_sorted = l.sorted, *p_bstart = l.bstart, *p_sstart = l.sstart, *p_big_list = l.big_list, *p_big_count = l.big_count;
-        if (phase == 2) {
-            // sorted in phase 1
-        } else if (borrowed) {
-            p_sorted = borrowed->sorted; p_bstart = borrowed->bstart; p_sstart = borrowed->sstart;
-            p_big_list = borrowed->big_list; p_big_count = borrowed->big_count;
-            ZK_HIP(hipStreamWaitEvent(st, borrowed->sorted_ready, 0));
-        } else {
         // digit rows are stored relative to the plan's first window; the kernels index them with absolute windows
         const uintptr_t dig_base = reinterpret_cast<uintptr_t>(this->d_dig) - (uintptr_t)pw_first * dstride * (wide ? 4 : 2);
         const uint16_t* d_dig = reinterpret_cast<const uint16_t*>(dig_base);
         const uint32_t* d_dig32 = reinterpret_cast<const uint32_t*>(dig_base);
         // general mode, small inputs: bucket-range partition (measured faster up to 2^18); otherwise the two-level sort
         const bool ranged = !pre && !wide && m < (1u << 19);
-        const bool two_level = !ranged && l.tmp_ref != nullptr;
+        const bool two_level = !ranged && l.tmp_ref != nullptr && opt.two_level_sort;
         if (two_level) {
             const int fl = fine_log_for(n);
             const uint32_t NB = B >> fl;
@@ -1654,27 +487,37 @@ struct MsmPlan : MsmPlanBase {
             const unsigned blocks = pre ? (unsigned)(w_count * nchunk) : (unsigned)(8 * ((w_count + 7) / 8) * nchunk);
             hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(SORT_THREADS), B * 4, st, d_dig, m, dstride, c, w_first, w_count, nchunk, ch_len, pre ? 1 : 0, (uint32_t)n, pw_first, l.hist, l.bstart, l.sorted);
         }
-        }  // !borrowed
-        if (phase != 2) ZK_HIP(hipEventRecord(l.ev_acc0, st));
-        if (phase == 1) return ZK_OK;
-        if (gate) ZK_HIP(hipStreamWaitEvent(st, gate, 0));
-        ZK_HIP(hipEventRecord(l.ev_accs, st));
-        // 5. accumulate
-        uint64_t lanes_needed = ((uint64_t)w_count * m + seg_len - 1) / seg_len;
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+
+    // stage 5: the dominant kernel; stage 6: buckets whose entries span several segments (three tiers, one launch)
+    int stage_accumulate(uint32_t m, uint32_t seg_len, hipStream_t st, const uint32_t* p_sorted, const uint32_t* p_bstart,
+                         const uint32_t* p_sstart, const uint32_t* p_big_list, const uint32_t* p_big_count) {
+        Work& l = ws;
+        const uint32_t n_keys = l.groups * B;
+        const uint64_t lanes_needed = ((uint64_t)l.w_count * m + seg_len - 1) / seg_len;
         hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((lanes_needed + 255) / 256)), dim3(256), 0, st, d_bases, p_sorted, p_bstart, p_sstart, n_keys, seg_len, l.partials, l.buckets);
         ZK_HIP(hipEventRecord(l.ev_acc1, st));
-        // 6. combine (three tiers, one launch)
         const uint32_t small_blocks = (2 * n_keys + COMBINE_THREADS - 1) / COMBINE_THREADS;
         hipLaunchKernelGGL(combine_kernel<G>, dim3(small_blocks + COMBINE_WAVE_BLOCKS + COMBINE_BIG_BLOCKS), dim3(COMBINE_THREADS), 0, st,
                            l.partials, p_sstart, n_keys, small_blocks, p_big_list, p_big_count, l.buckets);
-        if (borrowed) ZK_HIP(hipEventRecord(borrowed->release, st));  // the lender's buffers are no longer read
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+
+    // stage 7: sum_b (b + 1) B_b per bucket set down to (S, T) per block of row / column sums, copied to h_final
+    int stage_reduce(hipStream_t st) {
+        Work& l = ws;
+        const uint32_t groups = l.groups;
+        const uint32_t n_keys = groups * B;
         // 7. reduce: rows (sum over lo), cols (sum over hi), weighted sums
         uint32_t n_rows = groups * R, n_cols = groups * C;
         SumJob rows = {n_rows, R, B, C, 1u, C, 0u};
         SumJob cols = {n_cols, C, B, 1u, C, R, n_rows};
         // Two steps when the sums are long: one lane pair walks a run of K buckets with no idle lanes (the tree of the
         // one-step form leaves half of its lane-steps empty), then a short tree adds the R / K or C / K partial sums.
-        static const bool one_step = getenv("ZKMI_SUM_ONE_STEP") != nullptr;  // A/B knob
+        const bool one_step = opt.sum_one_step;  // A/B knob
         // worth it from 2^18 buckets on (8 windows of 2^15, or the 2^19-bucket set of a fixed-base plan): with fewer the sums
         // are a latency chain and the second launch only lengthens it (measured: 2^17 buckets 0.223 vs 0.212 ms)
         const uint32_t K = (one_step || n_keys < (1u << 18)) ? 0u : sum_part_len();
@@ -1692,7 +535,7 @@ struct MsmPlan : MsmPlanBase {
         } else {
         // lanes per output (two lanes = one point): many outputs (one bucket set per window) -> 16 pairs each walk
         // count/16 buckets and finish with a 4-level tree; few outputs (shared bucket set) -> 32 pairs, shortest chain
-        static const uint32_t lpo_env = getenv("ZKMI_LPO") ? (uint32_t)atoi(getenv("ZKMI_LPO")) : 0u;
+        const uint32_t lpo_env = opt.lanes_per_output;
         const uint32_t lpo = lpo_env ? lpo_env : ((n_rows + n_cols) >= 4096 ? 32u : 64u);
         hipLaunchKernelGGL(strided_sum_kernel<G>, dim3(((n_rows + n_cols) * lpo + 255) / 256), dim3(256), 0, st, l.buckets, l.rows, rows, cols, lpo);
         }
@@ -1700,13 +543,69 @@ struct MsmPlan : MsmPlanBase {
                            l.rows, R, groups, l.rows + (size_t)n_rows * XW, C, l.fin);
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipMemcpyAsync(h_final, l.fin, (size_t)groups * (bpr + bpc) * 2 * XW * 4, hipMemcpyDeviceToHost, st));
+        return ZK_OK;
+    }
+
+    // stages 2..7 + D2H
+    // `borrowed`: the digits and the sort of another plan's run over the same scalars (enqueue_shared); stages 1-4 are skipped
+    // phase: 0 = everything, 1 = up to the sorted entry list only, 2 = from the accumulate kernel on (after phase 1).
+    // gate: waited for right before the accumulate kernel (another plan's accumulate has finished), so that the
+    // accumulate kernels of several plans run one after the other while their sorts and reductions overlap.
+    int run_stages(uint32_t m, uint32_t dstride, hipStream_t st, const SortExport* borrowed = nullptr, int phase = 0, hipEvent_t gate = nullptr) {
+        Work& l = ws;
+        int rc;
+        const uint32_t seg_len = borrowed ? borrowed->seg_len : (phase == 2 ? l.seg_len : pick_seg_len((uint64_t)l.w_count * m));
+        l.seg_len = seg_len;
+        if (phase != 2) ZK_HIP(hipEventRecord(l.ev_begin, st));
+        const uint32_t *p_sorted = l.sorted, *p_bstart = l.bstart, *p_sstart = l.sstart, *p_big_list = l.big_list, *p_big_count = l.big_count;
+        if (phase == 2) {
+            // sorted in phase 1
+        } else if (borrowed) {
+            p_sorted = borrowed->sorted; p_bstart = borrowed->bstart; p_sstart = borrowed->sstart;
+            p_big_list = borrowed->big_list; p_big_count = borrowed->big_count;
+            ZK_HIP(hipStreamWaitEvent(st, borrowed->sorted_ready, 0));
+        } else if ((rc = stage_sort(m, dstride, seg_len, st))) {
+            return rc;
+        }
+        if (phase != 2) ZK_HIP(hipEventRecord(l.ev_acc0, st));
+        if (phase == 1) return ZK_OK;
+        if (gate) ZK_HIP(hipStreamWaitEvent(st, gate, 0));
+        ZK_HIP(hipEventRecord(l.ev_accs, st));
+        if ((rc = stage_accumulate(m, seg_len, st, p_sorted, p_bstart, p_sstart, p_big_list, p_big_count))) return rc;
+        if (borrowed) ZK_HIP(hipEventRecord(borrowed->release, st));  // the lender's buffers are no longer read
+        if ((rc = stage_reduce(st))) return rc;
         ZK_HIP(hipEventRecord(l.ev_done, st));
         return ZK_OK;
     }
 
+    int set_option(const char* name, int64_t value) override {
+        std::lock_guard<std::mutex> lock(mu);
+        if (q_pending || q_sorted) return fail(ZK_ERR_ARG, "MSM plan has a run in flight: options change between runs");
+        if (!strcmp(name, "segment_lanes")) {
+            if (value < 64) return fail(ZK_ERR_ARG, "segment_lanes must be at least 64");
+            // the partials buffer was sized for the creation-time target: more lanes than that would overrun it
+            if ((uint64_t)value > seg_lanes_at_init) return fail(ZK_ERR_ARG, "segment_lanes cannot exceed the value the plan was created with");
+            opt.segment_lanes = (uint64_t)value;
+        } else if (!strcmp(name, "sum_one_step")) {
+            opt.sum_one_step = value != 0;
+        } else if (!strcmp(name, "lanes_per_output")) {
+            if (value != 0 && (value < 2 || value > 64 || (value & (value - 1)))) return fail(ZK_ERR_ARG, "lanes_per_output: 0 or a power of two in [2, 64]");
+            opt.lanes_per_output = (uint32_t)value;
+        } else if (!strcmp(name, "two_level_sort")) {
+            if (value && !ws.tmp_ref) return fail(ZK_ERR_ARG, "the plan was created without the buffers of the two-level sort");
+            if (!value && wide) return fail(ZK_ERR_ARG, "windows wider than 16 bits exist in the two-level sort only");
+            opt.two_level_sort = value != 0;
+        } else {
+            return fail(ZK_ERR_ARG, std::string("unknown or creation-time MSM option: ") + name);
+        }
+        return ZK_OK;
+    }
+
+    uint64_t seg_lanes_at_init = 0;
     int create_flags = 0;
     int clone(MsmPlanBase** out) override {
         MsmPlan* p = new MsmPlan();
+        p->opt = opt;
         int rc = p->init(n_api, nullptr, 0, create_flags & ~ZK_MSM_HIGH_PRIORITY, c, pw_first, pw_count, this);
         if (rc) {
             delete p;

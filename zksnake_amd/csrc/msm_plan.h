@@ -3,6 +3,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <hip/hip_runtime.h>
 #include "../../include/zkmi.h"
@@ -72,7 +73,7 @@ struct MsmLayout {
 inline MsmLayout msm_layout(int scalar_bits, bool has_glv, uint64_t n_points, int flags, int window_bits, bool all_windows) {
     MsmLayout L;
     const bool pre = (flags & ZK_MSM_PRECOMPUTE) != 0;
-    static const bool no_glv = getenv("ZKMI_NO_GLV") != nullptr;
+    const bool no_glv = getenv("ZKMI_NO_GLV") != nullptr;   // read per call: the layout of a plan is fixed when it is created
     L.glv = has_glv && !pre && !(flags & ZK_MSM_NO_GLV) && !no_glv && n_points <= GLV_MAX_POINTS;
     L.entries = L.glv ? 2 * n_points : n_points;
     int c = window_bits > 0 ? window_bits : pick_window_bits(L.entries);
@@ -80,8 +81,8 @@ inline MsmLayout msm_layout(int scalar_bits, bool has_glv, uint64_t n_points, in
         // fixed-base plans over all windows: one shared bucket set makes wider windows affordable (13 windows of
         // 20 bits instead of 16 of 16: 19 % fewer additions) as long as a table reference fits the 31 bits below the sign of
         // a sort entry.  Window-sharded plans keep 16 windows, which split evenly over 2, 4 or 8 ranks.
-        static const int pre_c = getenv("ZKMI_PRE_C") ? atoi(getenv("ZKMI_PRE_C")) : 0;
-        static const bool no_two_level = getenv("ZKMI_NO_TWO_LEVEL") != nullptr;  // wide windows exist in the two-level sort only
+        const int pre_c = getenv("ZKMI_PRE_C") ? atoi(getenv("ZKMI_PRE_C")) : 0;
+        const bool no_two_level = getenv("ZKMI_NO_TWO_LEVEL") != nullptr;  // wide windows exist in the two-level sort only
         // Candidates whose TOP window is at least half full: all windows feed one bucket set, and a short top window
         // (18 bits: 3 scalar bits left for it) would pile its n entries into a handful of buckets of one coarse bin.
         const int cands[3] = {pre_c ? pre_c : MSM_WIDE_C_DEFAULT, 17, 0};
@@ -99,8 +100,41 @@ inline MsmLayout msm_layout(int scalar_bits, bool has_glv, uint64_t n_points, in
     return L;
 }
 
+// ---- per-plan tuning options ----------------------------------------------------------------------------------------
+// Defaults come from the ZKMI_* environment variables READ WHEN A PLAN IS CREATED (no process-wide latches: two plans of one
+// process may differ, and a test can flip a knob in-process); the run-time ones can also be changed on a live plan through
+// zk_msm_plan_set_option.  Layout options decide buffer sizes and the window layout and are fixed once the plan exists.
+struct MsmOptions {
+    // run-time (settable on a live plan)
+    uint64_t segment_lanes = 256ull * 1024;  // ZKMI_SEG_LANES: lanes the accumulate kernel aims at (4 waves per SIMD on 256 CUs)
+    bool sum_one_step = false;               // ZKMI_SUM_ONE_STEP: row / column sums in one launch whatever the bucket count
+    uint32_t lanes_per_output = 0;           // ZKMI_LPO: lanes per row / column sum of the one-step form (0 = by output count)
+    bool two_level_sort = true;              // ZKMI_NO_TWO_LEVEL clears it: one-level / bucket-range sorts only (c <= 16)
+    // layout (creation time only)
+    uint32_t sort_workgroups = 256;          // ZKMI_SORT_WGS: bucket-range sort workgroups over all windows
+    int fine_log = 0;                        // ZKMI_FINE_LOG: fine bucket bits of the two-level sort (0 = automatic)
+    bool trace_init = false;                 // ZKMI_TRACE_INIT: time the steps of plan creation on stderr
+
+    static MsmOptions from_env() {
+        MsmOptions o;
+        if (const char* e = getenv("ZKMI_SEG_LANES")) o.segment_lanes = (uint64_t)atoll(e);
+        o.sum_one_step = getenv("ZKMI_SUM_ONE_STEP") != nullptr;
+        if (const char* e = getenv("ZKMI_LPO")) o.lanes_per_output = (uint32_t)atoi(e);
+        o.two_level_sort = getenv("ZKMI_NO_TWO_LEVEL") == nullptr;
+        if (const char* e = getenv("ZKMI_SORT_WGS")) o.sort_workgroups = (uint32_t)atoi(e);
+        if (const char* e = getenv("ZKMI_FINE_LOG")) o.fine_log = atoi(e);
+        o.trace_init = getenv("ZKMI_TRACE_INIT") != nullptr;
+        return o;
+    }
+};
+
 struct MsmPlanBase {
     virtual ~MsmPlanBase() {}
+    MsmOptions opt = MsmOptions::from_env();
+    // name: "segment_lanes", "sum_one_step", "lanes_per_output", "two_level_sort"; ZK_ERR_ARG for anything else, for a value
+    // the plan cannot honour (two-level sort without its buffers, one-level sort for windows wider than 16 bits) and while a
+    // run is in flight
+    virtual int set_option(const char* name, int64_t value) = 0;
     virtual int export_sort(SortExport* out) = 0;                        // of the run in flight
     virtual int enqueue_shared(MsmPlanBase* lender, hipStream_t stream) = 0;
     // a second plan over the same bases (shared, read-only) with its own workspace and stream: two MSMs against one key

@@ -52,6 +52,7 @@ class Groth16:
         self._blinding = None   # tests may pin (r, s)
         self.precompute_keys = True  # proving-key MSM plans use the fixed-base table (ZK_MSM_PRECOMPUTE)
         self.last_timings = {}
+        self._collective_ms = 0.0
         self._live = []         # MSM plan handles with a run in flight (prove() cancels them when it fails half way)
         self._shard = None      # (rank, world, torch device or None) once shard_over_ranks() was called
 
@@ -249,9 +250,12 @@ class Groth16:
         from .._algebra import _point_class
         cid = self.E.curve.curve_id
         if self._shard is not None and self._shard[1] > 1:
+            import time
             from ..parallel import all_gather_limbs, sum_points
             flat = np.concatenate([p for p, _ in parts])
+            t0 = time.perf_counter()
             gathered = all_gather_limbs(flat, self._shard[2])  # (world, len)
+            self._collective_ms += (time.perf_counter() - t0) * 1e3
             totals, off = [], 0
             for p, group in parts:
                 totals.append(sum_points(cid, group, list(gathered[:, off:off + p.shape[0]])))
@@ -321,6 +325,7 @@ class Groth16:
     def _prove_msms(self, pk, res, early, ordered, r, s, q, t_start):
         import time
         t_qap = time.perf_counter()
+        self._collective_ms = 0.0
         n = res.n
         # The four MSMs over u, v, h run on their plans' own streams.  An accumulate kernel fills every wave slot of the
         # chip until it ends: left to themselves two of them only slow each other down and the sorts of the plans behind
@@ -374,8 +379,11 @@ class Groth16:
             B2 = msm_v2 + b2_fixed
             C = HZ + sum_delta_witness + A * s + B1 * r + c_fixed
         t_end = time.perf_counter()
+        # qap_ms is the part a window-sharded prover REPLICATES on every rank (witness upload, three sparse products, seven
+        # transforms); msm_* is what the ranks share; collective_ms the all_gather of the partial points inside the exchange
         self.last_timings = {"qap_ms": (t_qap - t_start) * 1e3, "msm_enqueue_ms": (t_enq - t_qap) * 1e3,
-                             "msm_finish_ms": (t_fin - t_enq) * 1e3, "exchange_assemble_ms": (t_end - t_fin) * 1e3}
+                             "msm_finish_ms": (t_fin - t_enq) * 1e3, "exchange_assemble_ms": (t_end - t_fin) * 1e3,
+                             "collective_ms": self._collective_ms}
         return Proof(A, B2, C)
 
     # ------------------------------------------------------------------------------------------
