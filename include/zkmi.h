@@ -111,7 +111,12 @@ int zk_point_limbs(int curve, int group); /* 64-bit limbs per affine point */
 int zk_ntt(int curve, int inverse, int coset, uint64_t n_in, const uint64_t* in, uint64_t size, uint64_t* out);
 
 /* mul_over_evaluation_domain / add_over_evaluation_domain (polynomial.rs:587-634): element-wise
- * over `size` entries; entries beyond n_a / n_b count as zero.  op: 0 = mul, 1 = add, 2 = sub. */
+ * over `size` entries; entries beyond n_a / n_b count as zero.  op: 0 = mul, 1 = add, 2 = sub.
+ * Deliberate divergence at THIS level: the reference's add_over_evaluation_domain indexes a[i], b[i] for every i < size
+ * and panics on a shorter input (polynomial.rs:594-597), while mul zero-pads (polynomial.rs:617-625); the C entry point zero-pads for
+ * every op (one kernel, and the PlonK prover adds vectors of unequal length).  The drop-in Python layer restores the
+ * reference's behaviour: `add_over_evaluation_domain` raises IndexError for a short input before it gets here
+ * (zksnake_amd/_algebra.py). */
 int zk_vec_op(int curve, int op, uint64_t size, uint64_t n_a, const uint64_t* a, uint64_t n_b, const uint64_t* b,
               uint64_t* out);
 
