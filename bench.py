@@ -34,6 +34,10 @@ from zksnake_amd import constant  # noqa: E402
 from zksnake_amd.parallel import all_gather_sum, window_ranges  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# chip-wide v_mad_u64_u32 issue rate, measured (tools/ubench2.hip, profiles/r03_ubench2_valu.log): 4.74 cycles per
+# wave-instruction per SIMD at eight waves per SIMD = 33.2 T/s at 2.4 GHz.  Rounds 1-2 quoted 26.4 T/s from a loop that
+# carried an extra add per multiply-add; the fractions reported against it were too flattering by a quarter.
+MAD_PEAK_T = 33.2
 BYTES_PER_PAIR = 96     # 32 B scalar + 64 B affine base (BN254 G1)
 
 
@@ -204,14 +208,14 @@ def main():
             },
             # the resource that actually binds: 32-bit integer multiply-add issue.  Per mixed addition the kernel
             # executes 8 products (2 N^2 = 162 v_mad_u64_u32 at N = 9 limbs, plus N v_mul_lo_u32) and 2 squarings (126); the
-            # peak is the measured chip-wide v_mad_u64_u32 rate (profiles/r01_ubench_valu.log: 26.4 T/s).
+            # peak is the measured chip-wide v_mad_u64_u32 rate (MAD_PEAK_T above).
             "roofline_valu": {
                 "kernel": "accumulate_kernel<Bn254G1>",
                 "bound": "int32 multiply-add issue (v_mad_u64_u32)",
                 "achieved": round(nwin.value * entries.value * MADS_PER_MIXED_ADD / acc_s / 1e12, 3) if acc_s > 0 and world == 1 else None,
-                "peak": 26.4,
+                "peak": MAD_PEAK_T,
                 "unit": "Tmad/s",
-                "frac": round(nwin.value * entries.value * MADS_PER_MIXED_ADD / acc_s / 1e12 / 26.4, 4) if acc_s > 0 and world == 1 else None,
+                "frac": round(nwin.value * entries.value * MADS_PER_MIXED_ADD / acc_s / 1e12 / MAD_PEAK_T, 4) if acc_s > 0 and world == 1 else None,
                 "mixed_additions_per_launch": nwin.value * entries.value,
             },
             "stage_ms": {
@@ -354,8 +358,8 @@ def extra_metrics(lib, torch, dev, args, bases, d_scalars, expected):
                                              "achieved": round(64 * m / ms / 1e6, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                              "frac": round(64 * m / ms / 1e6 / HBM_PEAK_GBPS, 5),
                                              "note": "64 B/element algorithmic (SURVEY 8d); the passes are bound by integer multiply-add issue"},
-                                "roofline_valu": {"achieved": round(11 * m * 162 / ms / 1e9, 3), "peak": 26.4, "unit": "Tmad/s",
-                                                  "frac": round(11 * m * 162 / ms / 1e9 / 26.4, 4),
+                                "roofline_valu": {"achieved": round(11 * m * 162 / ms / 1e9, 3), "peak": MAD_PEAK_T, "unit": "Tmad/s",
+                                                  "frac": round(11 * m * 162 / ms / 1e9 / MAD_PEAK_T, 4),
                                                   "note": "log2(n)/2 = 11 field products of 162 v_mad_u64_u32 per element"}}
     del d
 
@@ -506,7 +510,7 @@ def group_msm_metrics(lib, torch):
                          "host_tail": round(float(st[3]), 4)},
             "roofline": {"kernel": f"accumulate_kernel<{key}>", "bound": "hbm", "achieved": round(PAIR_BYTES[(cid, grp)] * n / acc_s / 1e9, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(PAIR_BYTES[(cid, grp)] * n / acc_s / 1e9 / HBM_PEAK_GBPS, 5)},
-            "roofline_valu": {"achieved": round(mads / acc_s / 1e12, 3), "peak": 26.4, "unit": "Tmad/s", "frac": round(mads / acc_s / 1e12 / 26.4, 4)}}
+            "roofline_valu": {"achieved": round(mads / acc_s / 1e12, 3), "peak": MAD_PEAK_T, "unit": "Tmad/s", "frac": round(mads / acc_s / 1e12 / MAD_PEAK_T, 4)}}
         N.check(lib.zk_msm_plan_destroy(h))
     return out
 
