@@ -173,3 +173,19 @@ def test_scalar_field_helpers(lib, name, cid):
             assert N.limbs_to_ints(o) == R.lagrange_at(n, tau % cv.r, cv)
     out = np.zeros(4, dtype=np.uint64)
     assert lib.zk_fr_root_of_unity(cid, 1 << 40, N.u64p(out)) == N.ZK_ERR_DOMAIN
+
+
+def test_relaxed_g2_step_host_build_and_integer_models(tmp_path):
+    """the relaxed-range G2 mixed addition of the accumulate kernel: (1) a host build of the library's own field / curve code
+    runs it against the plain formulas on chains of additions with the special cases (tests/native/relaxed_g2_check.cpp);
+    (2) the integer models replay its limb operations, and those of the lazy NTT butterfly, with every limb, column-sum
+    and value bound asserted on inputs pushed to the ends of their ranges (tools/model_relaxed_g2.py, tools/model_lazy_ntt.py)"""
+    import subprocess
+    import sys
+    exe = str(tmp_path / "relaxed_g2_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "relaxed_g2_check.cpp")])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and res.stdout.count(": ok") == 2, res.stdout + res.stderr
+    for model in ("model_relaxed_g2.py", "model_lazy_ntt.py"):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", model)], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr

@@ -117,6 +117,77 @@ ZK_HD void xyzz_add_affine(XYZZ<F>& acc, const Affine<F>& q) {
     acc.ZZZ = F::mul(acc.ZZZ, PPP);
 }
 
+// acc + (+-q) for the quadratic-extension groups with relaxed ranges, component by component (P = F::Params, every
+// component normalised):
+//   X in [0, 4p); Y, ZZ, ZZZ and the base in [0, 2p]
+//   P = U2 - X + 4p < 6p,  R = S2 - Y + 2p < 4p           carries only, no range selection
+//   PP = P^2 as ((P0 + P1)(P0 - P1 + 8p), (2 P0) P1): 12 * 14 = 168 <= R/p (169.3 for BN254 Fq), both < 2p;  RR likewise
+//   PPP = P PP, Q = X PP with the c1 of the left factor negated lazily against 8p
+//   X3 = RR - PPP + 2p - 2Q brought into [0, 4p) per component
+//   Y3 = R (Q - X3 + 4p) - Y PPP: nine limbs -> one four-product reduction per component (no subtraction at all),
+//        wider fields -> two products and an ordinary subtraction
+// tools/model_relaxed_g2.py replays this on integers with the limb, column and value bounds asserted; the host build of the
+// library runs the same code against the plain formulas (tests/test_host_lib.py).
+template <class F>
+ZK_HD void xyzz_add_affine_relaxed2(XYZZ<F>& acc, const Affine<F>& q, bool negate) {
+    typedef typename F::T T;
+    typedef typename F::Params P;
+    // the sentinel and an empty accumulator are exact zeros (written as such), so the limb test is enough here
+    if (F::is_zero_limbs(q.x) && F::is_zero_limbs(q.y)) return;
+    if (F::is_zero_limbs(acc.ZZ)) {
+        acc = {q.x, negate ? F::neg(q.y) : q.y, F::one(), F::one()};
+        return;
+    }
+    const T U2 = fp2_mul_relaxed<P, 4>(q.x, acc.ZZ);
+    // -y as 2p - y (normalised, <= 2p): a product operand like any other
+    T ny = {fp_sub_k<P, 2>(fp_zero<P>(), q.y.c0), fp_sub_k<P, 2>(fp_zero<P>(), q.y.c1)};
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        ny.c0.v[i] = negate ? ny.c0.v[i] : q.y.c0.v[i];
+        ny.c1.v[i] = negate ? ny.c1.v[i] : q.y.c1.v[i];
+    }
+    const T S2 = fp2_mul_relaxed<P, 4>(ny, acc.ZZZ);
+    const T Pd = {fp_sub_k<P, 4>(U2.c0, acc.X.c0), fp_sub_k<P, 4>(U2.c1, acc.X.c1)};
+    const T R = {fp_sub_k<P, 2>(S2.c0, acc.Y.c0), fp_sub_k<P, 2>(S2.c1, acc.Y.c1)};
+    const T PP = fp2_sqr_relaxed<P, 8>(Pd);
+    const T RR = fp2_sqr_relaxed<P, 4>(R);
+    if (fp_is_zero<P>(PP.c0) && fp_is_zero<P>(PP.c1)) {  // P^2 = 0 in the field: same x
+        if (fp_is_zero<P>(RR.c0) && fp_is_zero<P>(RR.c1)) {
+            Affine<F> d = q;
+            if (negate) d.y = F::neg(d.y);
+            acc = xyzz_dbl_affine<F>(d);
+        } else {
+            acc = xyzz_inf<F>();
+        }
+        return;
+    }
+    const T PPP = fp2_mul_relaxed<P, 8>(Pd, PP);
+    const T Q = fp2_mul_relaxed<P, 8>(acc.X, PP);
+    const T X3 = {fp_sub_twice_sel4<P>(fp_sub_k<P, 2>(RR.c0, PPP.c0), Q.c0), fp_sub_twice_sel4<P>(fp_sub_k<P, 2>(RR.c1, PPP.c1), Q.c1)};
+    const T D = {fp_sub_k<P, 4>(Q.c0, X3.c0), fp_sub_k<P, 4>(Q.c1, X3.c1)};   // < 6p
+    if constexpr (P::N <= 9) {
+        const Fp<P> nR1 = fp_neg_lazy_k<P, 8>(R.c1), nY0 = fp_neg_lazy_k<P, 4>(acc.Y.c0), nY1 = fp_neg_lazy_k<P, 4>(acc.Y.c1);
+        acc.Y = {fp_mul4<P>(R.c0, D.c0, nR1, D.c1, nY0, PPP.c0, acc.Y.c1, PPP.c1),
+                 fp_mul4<P>(R.c0, D.c1, nY0, PPP.c1, nY1, PPP.c0, R.c1, D.c0)};
+    } else {
+        acc.Y = fp2_sub<P>(fp2_mul_relaxed<P, 8>(R, D), fp2_mul_relaxed<P, 4>(acc.Y, PPP));
+    }
+    acc.X = X3;
+    acc.ZZ = fp2_mul_relaxed<P, 4>(acc.ZZ, PP);
+    acc.ZZZ = fp2_mul_relaxed<P, 4>(acc.ZZZ, PPP);
+}
+
+// The relaxed steps leave X in [0, 4p).  For the base-field groups every later use of X is a product, which does not mind; the
+// Fp2 arithmetic adds and subtracts components (fp2_sqr in the doublings of the reduction stages), so a lane that is done
+// accumulating brings X back below 2p before the point leaves its registers.
+template <class F>
+ZK_HD void xyzz_relaxed_finish(XYZZ<F>& acc) {
+    if constexpr (F::RELAXED2) {
+        typedef typename F::Params P;
+        acc.X = {fp_reduce_2p<P>(acc.X.c0), fp_reduce_2p<P>(acc.X.c1)};
+    }
+}
+
 #if defined(__HIPCC__)
 // Device form used by the MSM inner loop: the affine operand is read from memory (16-byte vector loads of
 // the packed Montgomery row) and dies right after U2/S2, so it does not occupy registers across the ten
@@ -178,6 +249,8 @@ __device__ __forceinline__ void xyzz_add_affine_mem(XYZZ<F>& acc, const uint32_t
         acc.X = X3;
         acc.ZZ = F::mul(acc.ZZ, PP);
         acc.ZZZ = F::mul(acc.ZZZ, PPP);
+    } else if constexpr (F::RELAXED2) {
+        xyzz_add_affine_relaxed2<F>(acc, load_affine_row<F>(src), negate);
     } else {
         T U2, S2;
         {

@@ -171,13 +171,13 @@ ZK_HD Fp<P> fp_sub_lazy(const Fp<P>& a, const Fp<P>& b) {
 // a - b + K p (K = 2 or 4) with the carries propagated (normalized limbs), for a < 2p and 0 <= b < K p: value in (0, (K+2)p)
 template <class P, int K>
 ZK_HD Fp<P> fp_sub_k(const Fp<P>& a, const Fp<P>& b) {
-    static_assert(K == 2 || K == 4, "K p constants exist for K = 2, 4");
+    static_assert(K == 2 || K == 4 || K == 8, "K p constants exist for K = 2, 4, 8");
     constexpr int N = P::N;
     Fp<P> r;
     int32_t c = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        int32_t x = (int32_t)a.v[i] - (int32_t)b.v[i] + (int32_t)(K == 2 ? P::P2[i] : P::P4[i]) + c;
+        int32_t x = (int32_t)a.v[i] - (int32_t)b.v[i] + (int32_t)(K == 2 ? P::P2[i] : (K == 4 ? P::P4[i] : P::P8[i])) + c;
         if (i < N - 1) {
             r.v[i] = (uint32_t)x & LIMB_MASK;
             c = x >> LIMB_BITS;
@@ -236,6 +236,48 @@ ZK_HD Fp<P> fp_neg_lazy(const Fp<P>& b) {
         uint32_t c = P::P4[i] + (i < P::N - 1 ? (1u << LIMB_BITS) : 0u) - (i > 0 ? 1u : 0u);
         r.v[i] = c - b.v[i];
     }
+    return r;
+}
+
+// K p - b (K = 4, 8) with the same borrow-proof limbs (< 2^30): a carry-free negation for ONE operand of a product.  The top
+// limb of K p does not borrow, so b must stay clear of it: b < (K - 1) p.
+template <class P, int K>
+ZK_HD Fp<P> fp_neg_lazy_k(const Fp<P>& b) {
+    static_assert(K == 4 || K == 8, "K p constants exist for K = 4, 8");
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        uint32_t c = (K == 4 ? P::P4[i] : P::P8[i]) + (i < P::N - 1 ? (1u << LIMB_BITS) : 0u) - (i > 0 ? 1u : 0u);
+        r.v[i] = c - b.v[i];
+    }
+    return r;
+}
+
+// a + b with the carries propagated and NO range selection: normalised limbs, the values simply add up
+template <class P>
+ZK_HD Fp<P> fp_add_nosel(const Fp<P>& a, const Fp<P>& b) {
+    constexpr int N = P::N;
+    Fp<P> r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t x = a.v[i] + b.v[i] + c;
+        if (i < N - 1) {
+            r.v[i] = x & LIMB_MASK;
+            c = x >> LIMB_BITS;
+        } else {
+            r.v[i] = x;
+        }
+    }
+    return r;
+}
+
+// 2a limb by limb (limbs < 2^30): one operand of a single product only
+template <class P>
+ZK_HD Fp<P> fp_dbl_lazy(const Fp<P>& a) {
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = a.v[i] << 1;
     return r;
 }
 
@@ -313,6 +355,49 @@ ZK_MUL Fp<P> fp_mul2(const Fp<P> a, const Fp<P> b, const Fp<P> c, const Fp<P> d)
         for (int i = k - N + 1; i < N; ++i) {
             acc += (uint64_t)a.v[i] * b.v[k - i];
             acc += (uint64_t)c.v[i] * d.v[k - i];
+        }
+#pragma unroll
+        for (int i = k - N + 1; i < N; ++i) acc += (uint64_t)m[i] * P::M[k - i];
+        r.v[k - N] = (uint32_t)acc & LIMB_MASK;
+        acc >>= LIMB_BITS;
+    }
+    r.v[N - 1] = (uint32_t)acc;
+    return r;
+}
+
+// a*b + c*d + e*f + g*h in ONE Montgomery reduction (the Y3 of an Fp2 mixed addition is exactly this shape).  Column room:
+// with b, d, f, h normalised, a and g normalised and c, e lazy negations (limbs < 2^30) a column holds
+// N (1 + 2 + 2 + 1 + 1) 2^58 = 63 * 2^58 < 2^64 for N = 9 only.  Value: the four products together must stay below R p.
+template <class P>
+ZK_MUL Fp<P> fp_mul4(const Fp<P> a, const Fp<P> b, const Fp<P> c, const Fp<P> d, const Fp<P> e, const Fp<P> f, const Fp<P> g, const Fp<P> h) {
+    constexpr int N = P::N;
+    static_assert(N <= 9, "four products and the reduction overflow the 64-bit column accumulators beyond nine limbs");
+    uint64_t acc = 0;
+    uint32_t m[N];
+    Fp<P> r;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) {
+            acc += (uint64_t)a.v[i] * b.v[k - i];
+            acc += (uint64_t)c.v[i] * d.v[k - i];
+            acc += (uint64_t)e.v[i] * f.v[k - i];
+            acc += (uint64_t)g.v[i] * h.v[k - i];
+        }
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P::M[k - i];
+        m[k] = ((uint32_t)acc * P::INV) & LIMB_MASK;
+        acc += (uint64_t)m[k] * P::M[0];
+        acc >>= LIMB_BITS;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; ++k) {
+#pragma unroll
+        for (int i = k - N + 1; i < N; ++i) {
+            acc += (uint64_t)a.v[i] * b.v[k - i];
+            acc += (uint64_t)c.v[i] * d.v[k - i];
+            acc += (uint64_t)e.v[i] * f.v[k - i];
+            acc += (uint64_t)g.v[i] * h.v[k - i];
         }
 #pragma unroll
         for (int i = k - N + 1; i < N; ++i) acc += (uint64_t)m[i] * P::M[k - i];
@@ -405,6 +490,28 @@ ZK_HD Fp<P> fp_reduce_full(const Fp<P>& a) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         int32_t w = (int32_t)a.v[i] - (int32_t)P::M[i] + c;
+        if (i < N - 1) {
+            t.v[i] = (uint32_t)w & LIMB_MASK;
+            c = w >> LIMB_BITS;
+        } else {
+            t.v[i] = (uint32_t)w;
+        }
+    }
+    const bool below = (int32_t)t.v[N - 1] < 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) t.v[i] = below ? a.v[i] : t.v[i];
+    return t;
+}
+
+// conditional subtraction of 2p: [0, 4p) -> [0, 2p)
+template <class P>
+ZK_HD Fp<P> fp_reduce_2p(const Fp<P>& a) {
+    constexpr int N = P::N;
+    Fp<P> t;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        int32_t w = (int32_t)a.v[i] - (int32_t)P::P2[i] + c;
         if (i < N - 1) {
             t.v[i] = (uint32_t)w & LIMB_MASK;
             c = w >> LIMB_BITS;
@@ -521,6 +628,23 @@ ZK_HD Fp2<P> fp2_sqr(const Fp2<P>& a) {
     return {t0, fp_dbl<P>(t1)};
 }
 
+// ---- relaxed-range Fp2 pieces of the G2 bucket accumulation (curve.cuh; bounds replayed by tools/model_relaxed_g2.py) ----
+// product with a.c1 negated lazily against K p (a.c1 < (K - 1) p): the components of a may exceed 2p as far as the value
+// bound of fp_mul2 allows, (a0 b0 + K p b1) <= R p and (a0 b1 + a1 b0) <= R p
+template <class P, int K>
+ZK_HD Fp2<P> fp2_mul_relaxed(const Fp2<P>& a, const Fp2<P>& b) {
+    const Fp<P> na1 = fp_neg_lazy_k<P, K>(a.c1);
+    return {fp_mul2<P>(a.c0, b.c0, na1, b.c1), fp_mul2<P>(a.c0, b.c1, a.c1, b.c0)};
+}
+// square with components below KD p / 2 ... precisely: ((a0 + a1)(a0 - a1 + KD p), (2 a0) a1), a1 < KD p; no range selection,
+// both results below 2p (the products reduce)
+template <class P, int KD>
+ZK_HD Fp2<P> fp2_sqr_relaxed(const Fp2<P>& a) {
+    const Fp<P> ts = fp_add_nosel<P>(a.c0, a.c1);
+    const Fp<P> td = fp_sub_k<P, KD>(a.c0, a.c1);
+    return {fp_mul<P>(ts, td), fp_mul<P>(fp_dbl_lazy<P>(a.c0), a.c1)};
+}
+
 template <class P>
 ZK_HD Fp2<P> fp2_inv(const Fp2<P>& a) {
     Fp<P> d = fp_inv<P>(fp_add<P>(fp_sqr<P>(a.c0), fp_sqr<P>(a.c1)));
@@ -569,6 +693,7 @@ struct FpOps {
 
     // ---- relaxed-range pieces of the bucket-accumulation step (curve.cuh, xyzz_add_affine_mem) ----
     static constexpr bool RELAXED = true;
+    static constexpr bool RELAXED2 = false;
     static ZK_HD T neg_for_mul(const T& a) { return fp_neg_lazy<P>(a); }                 // 4p - a, carry-free
     template <int K> static ZK_HD T sub_k(const T& a, const T& b) { return fp_sub_k<P, K>(a, b); }
     static ZK_HD T x3_sel4(const T& t, const T& q) { return fp_sub_twice_sel4<P>(t, q); }
@@ -592,6 +717,7 @@ struct Fp2Ops {
     static ZK_HD T add(const T& a, const T& b) { return fp2_add<P>(a, b); }
     static ZK_HD T sub(const T& a, const T& b) { return fp2_sub<P>(a, b); }
     static constexpr bool RELAXED = false;
+    static constexpr bool RELAXED2 = true;   // Fp2 form of the relaxed bucket-accumulation step (curve.cuh)
     static ZK_HD T sub_for_mul(const T& a, const T& b) { return fp2_sub<P>(a, b); }  // fp_mul2 has no spare room
     static ZK_HD T mul_diff(const T& m, const T& s, const T& x, const T& w, const T& y) {
         return fp2_sub<P>(fp2_mul<P>(m, fp2_sub<P>(s, x)), fp2_mul<P>(w, y));

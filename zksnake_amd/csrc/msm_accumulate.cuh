@@ -18,8 +18,13 @@ __device__ __forceinline__ uint32_t* run_slot(uint32_t* partials, uint32_t* buck
     return partials + (size_t)(r0 + t - bucket_start[key] / seg_len) * XW;
 }
 
+// Waves per SIMD the kernel is compiled for (a workgroup is four waves, one per SIMD).  The BN254 G2 step needs 265 registers
+// left to itself -- one wave per SIMD -- and fits the 256 of two waves at the price of seven spilled registers.
+template <class G> struct AccumulateWaves { static constexpr int PER_SIMD = 1; };
+template <> struct AccumulateWaves<Bn254G2> { static constexpr int PER_SIMD = 2; };
+
 template <class G>
-__global__ __launch_bounds__(256) void accumulate_kernel(const uint32_t* __restrict__ bases,
+__global__ __launch_bounds__(256, AccumulateWaves<G>::PER_SIMD) void accumulate_kernel(const uint32_t* __restrict__ bases,
                                                          const uint32_t* __restrict__ sorted,
                                                          const uint32_t* __restrict__ bucket_start,
                                                          const uint32_t* __restrict__ run_start, uint32_t n_keys,
@@ -45,6 +50,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const uint32_t* __restr
     for (uint32_t e = begin; e < end; ++e) {
         if (e == next) {
             // the bucket ends inside this segment: flush its run, move to the next non-empty bucket
+            xyzz_relaxed_finish<F>(acc);
             store_xyzz<F>(run_slot<F>(partials, buckets, run_start, bucket_start, key, t, seg_len), acc);
             acc = xyzz_inf<F>();
             do {
@@ -56,6 +62,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const uint32_t* __restr
         const uint32_t* src = bases + (size_t)(ref & 0x7FFFFFFFu) * AW;
         xyzz_add_affine_mem<F>(acc, src, (ref >> 31) != 0);
     }
+    xyzz_relaxed_finish<F>(acc);
     store_xyzz<F>(run_slot<F>(partials, buckets, run_start, bucket_start, key, t, seg_len), acc);
 }
 

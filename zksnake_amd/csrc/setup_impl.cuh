@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void fixed_mul_kernel(const uint32_t* __restri
             xyzz_add_affine_mem<F>(acc, table + ((size_t)j * FIXED_HALF + d - 1) * AW, v < 0);
         }
     }
+    xyzz_relaxed_finish<F>(acc);
     st_coord<F>(temp + i * XW, acc.X);
     st_coord<F>(temp + i * XW + L, acc.Y);
     st_coord<F>(temp + i * XW + 2 * L, acc.ZZ);
