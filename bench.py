@@ -525,7 +525,12 @@ def mads_per_mixed_add(cid, grp):
     one double product; G2 (Fp2): a product is two double products, a squaring two products"""
     nl = 9 if cid == 0 else 14
     mul, sqr, mul2 = 2 * nl * nl, nl * (nl + 1) // 2 + nl * nl, 3 * nl * nl
-    return 6 * mul + 2 * sqr + mul2 if grp == 1 else 8 * (2 * mul2) + 2 * (2 * mul)
+    if grp == 1:
+        return 6 * mul + 2 * sqr + mul2
+    # G2 (relaxed Fp2 step): six Fp2 products of two double products, two squares of two products, and Y3 -- for nine limbs one
+    # four-product reduction per component (5 N^2), for wider fields two more Fp2 products
+    y3 = 2 * 5 * nl * nl if nl <= 9 else 2 * (2 * mul2)
+    return 6 * (2 * mul2) + 2 * (2 * mul) + y3
 
 
 def prove_cpu_baseline(g, A, B, C, w, threads):
