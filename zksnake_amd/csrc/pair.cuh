@@ -132,6 +132,42 @@ __device__ __forceinline__ HalfPt<F> pair_add(const HalfPt<F>& p, const HalfPt<F
     typedef typename F::T T;
     if (half_is_inf<F>(q)) return p;
     if (half_is_inf<F>(p)) return q;
+    if constexpr (F::RELAXED) {
+        // Base-field groups: the differences that only feed products skip the range selection (carries only), as in the
+        // accumulate step (curve.cuh): 480 -> 268 instructions outside the seven products of the chain.  X may sit in [0, 4p)
+        // (it only ever meets products); Y, ZZ, ZZZ stay below 2p (Y is doubled with a range-selecting addition in xyzz_dbl).
+        //   d = m2 - m1 + 2p < 4p;  dd = d^2 (16 <= R/p);  PPP = d dd (8);  X3 = RR - PPP + 2p - 2Q in [0, 4p);
+        //   Q - X3 + 4p < 6p;  R (Q - X3) (4 * 6 = 24)
+        const T m1 = F::mul(p.a, q.b);   // U1 | S1
+        const T m2 = F::mul(q.a, p.b);   // U2 | S2
+        const T d = F::template sub_k<2>(m2, m1);   // P | R, in (0, 4p)
+        const T dd = F::sqr(d);                     // PP | RR: zero exactly when d is zero mod p
+        const bool dz = F::is_zero(dd);
+        const bool dz_other = pair_xch_flag(dz);
+        if (dz || dz_other) {
+            const bool p_zero = odd ? dz_other : dz, r_zero = odd ? dz : dz_other;
+            if (p_zero) {
+                if (!r_zero) return half_inf<F>();  // P = -Q
+                const T oa = pair_xch<T>(p.a), ob = pair_xch<T>(p.b);
+                XYZZ<F> full = odd ? XYZZ<F>{oa, p.a, ob, p.b} : XYZZ<F>{p.a, oa, p.b, ob};
+                full = xyzz_dbl<F>(full);
+                return odd ? HalfPt<F>{full.Y, full.ZZZ} : HalfPt<F>{full.X, full.ZZ};
+            }
+        }
+        const T t4 = F::mul(pair_sel<T>(odd, d, p.b), pair_sel<T>(odd, dd, q.b));   // PPP | ZZZ12
+        const T x_dd = pair_xch<T>(dd);                                    // even: RR, odd: PP
+        const T x_t4 = pair_xch<T>(t4);                                    // odd: PPP
+        const T t5 = F::mul(pair_sel<T>(odd, m1, t4), pair_sel<T>(odd, dd, x_t4));  // Q | ZZZ3
+        const T x3 = F::x3_sel4(F::template sub_k<2>(x_dd, t4), t5);      // even: X3 in [0, 4p) (odd: unused)
+        const T qx = F::template sub_k<4>(t5, x3);                         // even: Q - X3 + 4p
+        const T x_qx = pair_xch<T>(qx);
+        const T t6 = F::mul(pair_sel<T>(odd, p.b, d), pair_sel<T>(odd, q.b, x_qx));  // ZZ12 | R (Q - X3)
+        const T t7 = F::mul(pair_sel<T>(odd, t6, m1), pair_sel<T>(odd, dd, x_t4));   // ZZ3  | S1 PPP
+        HalfPt<F> r;
+        r.a = pair_sel<T>(odd, x3, F::sub(t6, t7));
+        r.b = pair_sel<T>(odd, t7, t5);
+        return r;
+    }
     const T m1 = F::mul(p.a, q.b);   // U1 | S1
     const T m2 = F::mul(q.a, p.b);   // U2 | S2
     const T d = F::sub(m2, m1);      // P  | R
