@@ -717,7 +717,12 @@ struct Fp2Ops {
     static ZK_HD T add(const T& a, const T& b) { return fp2_add<P>(a, b); }
     static ZK_HD T sub(const T& a, const T& b) { return fp2_sub<P>(a, b); }
     static constexpr bool RELAXED = false;
-    static constexpr bool RELAXED2 = true;   // Fp2 form of the relaxed bucket-accumulation step (curve.cuh)
+    static constexpr bool RELAXED2 = true;   // Fp2 form of the relaxed bucket-accumulation step (curve.cuh) and of pair_add (pair.cuh)
+    template <int K> static ZK_HD T sub_k(const T& a, const T& b) { return {fp_sub_k<P, K>(a.c0, b.c0), fp_sub_k<P, K>(a.c1, b.c1)}; }
+    static ZK_HD T x3_sel4(const T& t, const T& q) { return {fp_sub_twice_sel4<P>(t.c0, q.c0), fp_sub_twice_sel4<P>(t.c1, q.c1)}; }
+    template <int K> static ZK_HD T mul_rel(const T& a, const T& b) { return fp2_mul_relaxed<P, K>(a, b); }   // a.c1 < (K - 1) p
+    template <int KD> static ZK_HD T sqr_rel(const T& a) { return fp2_sqr_relaxed<P, KD>(a); }                // a.c1 < KD p
+    static ZK_HD T reduce_2p(const T& a) { return {fp_reduce_2p<P>(a.c0), fp_reduce_2p<P>(a.c1)}; }
     static ZK_HD T sub_for_mul(const T& a, const T& b) { return fp2_sub<P>(a, b); }  // fp_mul2 has no spare room
     static ZK_HD T mul_diff(const T& m, const T& s, const T& x, const T& w, const T& y) {
         return fp2_sub<P>(fp2_mul<P>(m, fp2_sub<P>(s, x)), fp2_mul<P>(w, y));

@@ -168,6 +168,42 @@ __device__ __forceinline__ HalfPt<F> pair_add(const HalfPt<F>& p, const HalfPt<F
         r.b = pair_sel<T>(odd, t7, t5);
         return r;
     }
+    if constexpr (F::RELAXED2) {
+        // Quadratic-extension groups, the same relaxation component by component (bounds as in xyzz_add_affine_relaxed2):
+        // X in [0, 4p) -- it meets products with its c1 negated against 8p -- Y, ZZ, ZZZ below 2p;
+        //   d = m2 - m1 + 2p < 4p;  dd = d^2 as ((d0 + d1)(d0 - d1 + 4p), (2 d0) d1): 8 * 8 = 64 <= R/p;
+        //   PPP = d dd: 4*2 + 8*2 = 24;  Q - X3 + 4p < 6p;  R (Q - X3): 4*6 + 8*6 = 72 <= 169
+        const T m1 = F::template mul_rel<8>(p.a, q.b);   // U1 | S1
+        const T m2 = F::template mul_rel<8>(q.a, p.b);   // U2 | S2
+        const T d = F::template sub_k<2>(m2, m1);        // P | R, components in (0, 4p)
+        const T dd = F::template sqr_rel<4>(d);          // PP | RR, below 2p: zero exactly when d is zero in the field
+        const bool dz = F::is_zero(dd);
+        const bool dz_other = pair_xch_flag(dz);
+        if (dz || dz_other) {
+            const bool p_zero = odd ? dz_other : dz, r_zero = odd ? dz : dz_other;
+            if (p_zero) {
+                if (!r_zero) return half_inf<F>();  // P = -Q
+                const T oa = pair_xch<T>(p.a), ob = pair_xch<T>(p.b);
+                XYZZ<F> full = odd ? XYZZ<F>{oa, p.a, ob, p.b} : XYZZ<F>{p.a, oa, p.b, ob};
+                full.X = F::reduce_2p(full.X);      // the plain doubling adds and subtracts components of X
+                full = xyzz_dbl<F>(full);
+                return odd ? HalfPt<F>{full.Y, full.ZZZ} : HalfPt<F>{full.X, full.ZZ};
+            }
+        }
+        const T t4 = F::template mul_rel<8>(pair_sel<T>(odd, d, p.b), pair_sel<T>(odd, dd, q.b));   // PPP | ZZZ12
+        const T x_dd = pair_xch<T>(dd);                                    // even: RR, odd: PP
+        const T x_t4 = pair_xch<T>(t4);                                    // odd: PPP
+        const T t5 = F::mul(pair_sel<T>(odd, m1, t4), pair_sel<T>(odd, dd, x_t4));  // Q | ZZZ3
+        const T x3 = F::x3_sel4(F::template sub_k<2>(x_dd, t4), t5);      // even: X3 in [0, 4p) (odd: unused)
+        const T qx = F::template sub_k<4>(t5, x3);                         // even: Q - X3 + 4p
+        const T x_qx = pair_xch<T>(qx);
+        const T t6 = F::template mul_rel<8>(pair_sel<T>(odd, p.b, d), pair_sel<T>(odd, q.b, x_qx));  // ZZ12 | R (Q - X3)
+        const T t7 = F::mul(pair_sel<T>(odd, t6, m1), pair_sel<T>(odd, dd, x_t4));   // ZZ3  | S1 PPP
+        HalfPt<F> r;
+        r.a = pair_sel<T>(odd, x3, F::sub(t6, t7));
+        r.b = pair_sel<T>(odd, t7, t5);
+        return r;
+    }
     const T m1 = F::mul(p.a, q.b);   // U1 | S1
     const T m2 = F::mul(q.a, p.b);   // U2 | S2
     const T d = F::sub(m2, m1);      // P  | R
