@@ -183,10 +183,12 @@ int zk_batch_mul(int curve, int group, uint64_t n, const uint64_t* scalars, cons
  * shares one bucket set (uses n * windows * point bytes of HBM); window_bits 0 = automatic. */
 #define ZK_MSM_PRECOMPUTE 1
 #define ZK_MSM_HIGH_PRIORITY 2 /* the plan's own stream (ZK_STREAM_PLAN) gets the top stream priority */
-/* General (not ZK_MSM_PRECOMPUTE) G1 plans of up to 2^22 points split every scalar with the curve's endomorphism,
- * k = k1 + lambda k2 with |k1|, |k2| < 2^127, and run over the 2n points (P_i, (beta x_i, y_i)): the same number of bucket
- * additions in half the windows, so half the bucket sets to reduce and half the doublings in the tail.  The result is the
- * same point.  This flag (or ZKMI_NO_GLV=1 in the environment) keeps the plain 254/255-bit windows. */
+/* General (not ZK_MSM_PRECOMPUTE) plans of up to 2^22 points split every scalar with the group's endomorphism,
+ * k = k1 + lambda k2 with |k1|, |k2| < 2^127, and run over the 2n points (P_i, phi(P_i)) -- phi = (beta x, y) on G1, the squared
+ * untwist-Frobenius-twist map (c x, -y) on G2: the same number of bucket additions in half the windows, so half the bucket
+ * sets to reduce and half the doublings in the tail.  The result is the same point.  This flag (or ZKMI_NO_GLV=1 in the
+ * environment) keeps the plain 254/255-bit windows.  Two split-scalar plans share a sort (zk_msm_plan_enqueue_shared) only
+ * within one group: G1 and G2 split against different eigenvalues. */
 #define ZK_MSM_NO_GLV 4
 int zk_msm_plan_create(int curve, int group, uint64_t n, const void* bases, int bases_on_device, int flags,
                        int window_bits, uint64_t* handle);

@@ -506,6 +506,21 @@ def test_shared_sort_between_g1_and_g2_plans(gpu, flags, n):
         assert (o1 == singles[(1, "a")]).all()
         N.check(gpu.zk_msm_plan_destroy(hs))
         if flags == N.MSM_NO_GLV:
+            # two split-scalar plans of different groups: each splits against its own eigenvalue, the digits do not mix
+            b1, _ = _bases_from_library(gpu, cid, 1, n, 0xC0FFEE + 1)
+            b2, _ = _bases_from_library(gpu, cid, 2, n, 0xC0FFEE + 2)
+            hg1, hg2 = N._u64(0), N._u64(0)
+            N.check(gpu.zk_msm_plan_create(cid, 1, n, b1.ctypes.data, 0, 0, 0, hg1))
+            N.check(gpu.zk_msm_plan_create(cid, 2, n, b2.ctypes.data, 0, 0, 0, hg2))
+            N.check(gpu.zk_msm_plan_enqueue(hg1, n, sc.ctypes.data, 0, 0, 0, N.STREAM_PLAN))
+            assert gpu.zk_msm_plan_enqueue_shared(hg2, hg1, N.STREAM_PLAN) == N.ZK_ERR_ARG
+            N.check(gpu.zk_msm_plan_finish(hg1, N.u64p(o1)))
+            assert (o1 == singles[(1, "a")]).all()
+            o2 = np.zeros(16, dtype=np.uint64)
+            N.check(gpu.zk_msm_plan_run(hg2, n, sc.ctypes.data, 0, 0, 0, N.u64p(o2), None))
+            assert (o2 == singles[(2, "a")]).all()       # the split-scalar G2 plan agrees with the plain one
+            N.check(gpu.zk_msm_plan_destroy(hg1))
+            N.check(gpu.zk_msm_plan_destroy(hg2))
             # a general G1 plan that splits its scalars with the endomorphism sorts 2n half-scalars: nothing a G2 plan could use
             bases1, _ = _bases_from_library(gpu, cid, 1, n, 0xC0FFEE + 1)
             hg = N._u64(0)
@@ -596,8 +611,9 @@ def test_two_step_enqueue_orders_the_accumulate_kernels(gpu, flags):
             N.check(gpu.zk_msm_plan_destroy(h))
 
 
+@pytest.mark.parametrize("grp", [1, 2])
 @pytest.mark.parametrize("name,cid", CURVES)
-def test_split_scalar_plan_on_the_decomposition_corner_cases(gpu, name, cid):
+def test_split_scalar_plan_on_the_decomposition_corner_cases(gpu, name, cid, grp):
     """scalars at and around lambda, r - lambda, the thirds of r, powers of two and their negatives: the places where the
     short-lattice rounding of the split-scalar digits kernel changes sign or carries"""
     import importlib.util
@@ -605,29 +621,32 @@ def test_split_scalar_plan_on_the_decomposition_corner_cases(gpu, name, cid):
     spec = importlib.util.spec_from_file_location("gen_glv_params", os.path.join(os.path.dirname(__file__), "..", "tools", "gen_glv_params.py"))
     G = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(G)
-    cs = G.constants("Bn254" if cid == 0 else "Bls381")
+    cs = G.constants("Bn254" if cid == 0 else "Bls381") if grp == 1 else G.constants_g2("Bn254G2" if cid == 0 else "Bls381G2")
     cv = pyref.curve_by_name(name)
     r, lam = cv.r, cs["lam"]
     vals = [0, 1, 2, r - 1, r - 2, r // 2, r // 2 + 1, lam, lam + 1, lam - 1, r - lam, r - lam + 1, (r - 1) // 3, 2 * (r - 1) // 3,
             lam * lam % r, (lam * lam + 1) % r, cs["a1"] % r, (-cs["b1"]) % r, cs["a2"] % r, cs["b2"] % r]
     vals += [(1 << b) % r for b in range(0, 256, 7)] + [(r - (1 << b)) % r for b in range(0, 254, 9)]
     n = len(vals)
-    _, bases = oracle_bases(cid, 1, n, 123)
+    _, bases = oracle_bases(cid, grp, n, 123)
     sc = N.ints_to_limbs(vals, 4)
-    exp = corc.msm(cid, 1, sc, bases, threads=8)
+    exp = corc.msm(cid, grp, sc, bases, threads=8)
     for flags in (0, N.MSM_NO_GLV):
         for c in (0, 16, 13):
             h = N._u64(0)
-            N.check(gpu.zk_msm_plan_create(cid, 1, n, bases.ctypes.data, 0, flags, c, h))
-            out = np.zeros(N.point_limbs(cid, 1), dtype=np.uint64)
+            N.check(gpu.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, flags, c, h))
+            ent = N._u64(0)
+            N.check(gpu.zk_msm_plan_entries(h, ent))
+            assert ent.value == (n if flags else 2 * n)      # every group splits its scalars unless told not to
+            out = np.zeros(N.point_limbs(cid, grp), dtype=np.uint64)
             N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, 0, 0, N.u64p(out), None))
             N.check(gpu.zk_msm_plan_destroy(h))
             assert (out == exp).all(), (flags, c)
     # every scalar alone against one base: a wrong half-scalar cannot hide in a sum
     for i in range(n):
-        one = np.zeros(N.point_limbs(cid, 1), dtype=np.uint64)
-        N.check(gpu.zk_msm(cid, 1, 1, 1, N.u64p(sc[i:i + 1].copy()), N.u64p(bases[i:i + 1].copy()), N.u64p(one)))
-        assert (one == corc.msm(cid, 1, sc[i:i + 1], bases[i:i + 1], threads=1)).all(), vals[i]
+        one = np.zeros(N.point_limbs(cid, grp), dtype=np.uint64)
+        N.check(gpu.zk_msm(cid, grp, 1, 1, N.u64p(sc[i:i + 1].copy()), N.u64p(bases[i:i + 1].copy()), N.u64p(one)))
+        assert (one == corc.msm(cid, grp, sc[i:i + 1], bases[i:i + 1], threads=1)).all(), vals[i]
 
 
 def test_point_array_plan_cache_follows_the_window_layout(gpu):

@@ -65,6 +65,7 @@ struct Bn254G1 {
     typedef HostTail64<Fp64Ops<BnFqParams>> HostF;  // 64-bit-limb host arithmetic (host64.cuh)
     typedef BnFrParams Fr;
     static constexpr int CURVE = ZK_CURVE_BN254, GROUP = ZK_G1;
+    static constexpr int ENDO_ID = 2 * CURVE + GROUP;   // identity of the group's scalar split (SortExport::endo)
     static constexpr int FQ64 = 4;  // 64-bit limbs per base field element
 };
 struct Bn254G2 {
@@ -72,6 +73,7 @@ struct Bn254G2 {
     typedef HostTail64<Fp2Ops64<BnFqParams>> HostF;
     typedef BnFrParams Fr;
     static constexpr int CURVE = ZK_CURVE_BN254, GROUP = ZK_G2;
+    static constexpr int ENDO_ID = 2 * CURVE + GROUP;
     static constexpr int FQ64 = 4;
 };
 struct Bls381G1 {
@@ -79,6 +81,7 @@ struct Bls381G1 {
     typedef HostTail64<Fp64Ops<BlsFqParams>> HostF;
     typedef BlsFrParams Fr;
     static constexpr int CURVE = ZK_CURVE_BLS12_381, GROUP = ZK_G1;
+    static constexpr int ENDO_ID = 2 * CURVE + GROUP;
     static constexpr int FQ64 = 6;
 };
 struct Bls381G2 {
@@ -86,6 +89,7 @@ struct Bls381G2 {
     typedef HostTail64<Fp2Ops64<BlsFqParams>> HostF;
     typedef BlsFrParams Fr;
     static constexpr int CURVE = ZK_CURVE_BLS12_381, GROUP = ZK_G2;
+    static constexpr int ENDO_ID = 2 * CURVE + GROUP;
     static constexpr int FQ64 = 6;
 };
 

@@ -152,7 +152,7 @@ int zk_msm_window_layout(int curve, int group, uint64_t n, int flags, int window
     if (curve != ZK_CURVE_BN254 && curve != ZK_CURVE_BLS12_381) return fail(ZK_ERR_ARG, "unknown curve");
     if (group != ZK_G1 && group != ZK_G2) return fail(ZK_ERR_ARG, "unknown group");
     const int bits = curve == ZK_CURVE_BN254 ? BnFrParams::BITS : BlsFrParams::BITS;
-    const MsmLayout lay = msm_layout(bits, group == ZK_G1, n, flags, window_bits, false);
+    const MsmLayout lay = msm_layout(bits, true /* all four groups split their scalars */, n, flags, window_bits, false);
     if (lay.c < 2 || lay.c > 20) return fail(ZK_ERR_ARG, "window bits must be in [2, 20]");
     *window_bits_out = lay.c;
     *n_windows = lay.nwin;

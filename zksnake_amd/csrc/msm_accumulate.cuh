@@ -82,8 +82,15 @@ __global__ void bases_to_mont_kernel(const uint32_t* __restrict__ in, uint64_t n
     p.y = F::from_canonical(w + F::LIMBS);
     if constexpr (GlvOf<G>::OK) {
         if (glv) {
+            typedef typename F::Params FP;
             store_affine<F>(out + 2 * i * AW, p);
-            p.x = F::mul(p.x, F::from_canonical(GlvOf<G>::P::BETA));
+            const Fp<FP> beta = fp_from_canonical<FP>(GlvOf<G>::P::BETA);
+            if constexpr (GlvOf<G>::P::NEG_Y) {   // G2: (c x, -y), c in the base field
+                p.x = {fp_mul<FP>(p.x.c0, beta), fp_mul<FP>(p.x.c1, beta)};
+                p.y = F::neg(p.y);
+            } else {                              // G1: (beta x, y)
+                p.x = fp_mul<FP>(p.x, beta);
+            }
             store_affine<F>(out + (2 * i + 1) * AW, p);
             return;
         }

@@ -101,5 +101,9 @@ constexpr uint32_t COMBINE_WAVE_MAX = 2048;   // <= 2048 runs: one wave per buck
 template <class G> struct GlvOf { static constexpr bool OK = false; };
 template <> struct GlvOf<Bn254G1> { static constexpr bool OK = true; typedef Bn254Glv P; };
 template <> struct GlvOf<Bls381G1> { static constexpr bool OK = true; typedef Bls381Glv P; };
+// G2: psi^2 (x, y) = (c x, -y) with c in Fp (tools/gen_glv_params.py); its eigenvalue differs from G1's, so a split-scalar
+// G1 plan and a split-scalar G2 plan cannot share digits or a sort (SortExport::endo)
+template <> struct GlvOf<Bn254G2> { static constexpr bool OK = true; typedef Bn254G2Glv P; };
+template <> struct GlvOf<Bls381G2> { static constexpr bool OK = true; typedef Bls381G2Glv P; };
 
 }  // namespace zkmi

@@ -710,6 +710,7 @@ struct MsmPlan : MsmPlanBase {
         out->n = n; out->m = q_m; out->seg_len = ws.seg_len; out->groups = ws.groups;
         out->c = c; out->nwin = nwin; out->w_first = q_first; out->w_count = q_count;
         out->pw_first = pw_first; out->pw_count = pw_count; out->scalar_bits = FrP::BITS; out->pre = pre; out->glv = glv;
+        out->endo = glv ? G::ENDO_ID : 0;
         out->sorted_ready = ws.ev_acc0;
         out->release = ws.ev_release;
         ws.lent = true;
@@ -725,7 +726,7 @@ struct MsmPlan : MsmPlanBase {
         if (rc) return rc;
         std::lock_guard<std::mutex> lock(mu);
         if (q_pending || q_sorted) return fail(ZK_ERR_ARG, "MSM plan already has a run in flight: call zk_msm_plan_finish first");
-        if (ex.n != n || ex.c != c || ex.nwin != nwin || ex.pre != pre || ex.glv != glv || ex.scalar_bits != FrP::BITS ||
+        if (ex.n != n || ex.c != c || ex.nwin != nwin || ex.pre != pre || ex.glv != glv || ex.endo != (glv ? G::ENDO_ID : 0) || ex.scalar_bits != FrP::BITS ||
             ex.pw_first != pw_first || ex.pw_count != pw_count)
             return fail(ZK_ERR_ARG, "plans differ in size, window layout or mode: the sort cannot be shared");
         if (ws.lent) {

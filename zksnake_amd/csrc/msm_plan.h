@@ -25,6 +25,7 @@ struct SortExport {
     uint32_t m = 0, seg_len = 0, groups = 0;
     int c = 0, nwin = 0, w_first = 0, w_count = 0, pw_first = 0, pw_count = 0, scalar_bits = 0;
     bool pre = false, glv = false;
+    int endo = 0;                       // which endomorphism split the scalars (curve * 2 + group; 0 = none): digits of different splits do not mix
     hipEvent_t sorted_ready = nullptr;  // recorded on the lender's stream after its sort stage
     hipEvent_t release = nullptr;       // the borrower records it after its last read; the lender's next run waits for it
 };
