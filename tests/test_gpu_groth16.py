@@ -475,3 +475,24 @@ def test_any_failure_half_way_through_prove_cancels_the_runs_in_flight(gpu, monk
     monkeypatch.setattr(Groth16, "_finish_msm", real_finish)
     again = g.prove(w[:2], w[2:])
     assert again.to_bytes() == good.to_bytes() and g.verify(again, w[:2])
+
+
+@pytest.mark.parametrize("curve", ["BN254", "BLS12_381"])
+def test_prove_with_general_plans_split_scalars_on_every_group(gpu, curve):
+    """precompute_keys = False: the key's MSM plans are general plans, which split their scalars with the group's endomorphism
+    -- G1 and G2 against different eigenvalues, so the G2 plan cannot borrow the G1 plan's sort (it is refused and sorts
+    for itself); the proof bytes equal those of the fixed-base plans and the closed form"""
+    cv = pyref.curve_by_name(curve)
+    n = 1 << 10
+    A, B, C, w, n_col = W.chain_circuit(n, cv.r)
+    proofs = []
+    for pre in (True, False):
+        g = Groth16(R1CS.from_triplets(A, B, C, n, n_col, 2, curve), curve)
+        g._toxic, g._blinding = TOXIC, BLIND
+        g.precompute_keys = pre
+        g.setup()
+        p1 = g.prove(w[:2], w[2:])
+        p2 = g.prove(w[:2], w[2:])      # plans reused
+        assert p1.to_bytes() == p2.to_bytes() and g.verify(p1, w[:2])
+        proofs.append(p1.to_bytes())
+    assert proofs[0] == proofs[1]
