@@ -24,7 +24,7 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libzk_oracle.so")
+        path = os.environ.get("ZK_ORACLE_LIB") or os.path.join(_HERE, "libzk_oracle.so")   # ZK_ORACLE_LIB: sanitizer build
         if not os.path.exists(path):
             build()
         _LIB = ctypes.CDLL(path)

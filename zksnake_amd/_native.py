@@ -255,7 +255,14 @@ def point_limbs(cid, group):
 # ---- int <-> limb marshalling (the reference marshals Python ints through pyo3 BigUint) ----
 
 try:  # CPython helper built beside libzkmi.so (csrc/pyints.c); marshalling only
-    from . import _pyints
+    if os.environ.get("ZKMI_PYINTS"):   # another build of the helper (tools/sanitize_cpu.sh)
+        import importlib.machinery
+        import importlib.util
+        _ldr = importlib.machinery.ExtensionFileLoader("zksnake_amd._pyints", os.environ["ZKMI_PYINTS"])
+        _pyints = importlib.util.module_from_spec(importlib.util.spec_from_loader("zksnake_amd._pyints", _ldr))
+        _ldr.exec_module(_pyints)
+    else:
+        from . import _pyints
 except ImportError:  # pragma: no cover - e.g. a different interpreter than the one it was built for
     _pyints = None
 
