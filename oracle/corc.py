@@ -33,6 +33,7 @@ def lib():
         _LIB.orc_batch_mul.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u64p, u64p, ctypes.c_int, u64p, ctypes.c_int]
         _LIB.orc_point_add.argtypes = [ctypes.c_int, ctypes.c_int, u64p, u64p, u64p]
         _LIB.orc_ntt.argtypes = [ctypes.c_int, u64p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        _LIB.orc_ntt_spot.argtypes = [ctypes.c_int, u64p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u64p, ctypes.c_int]
         _LIB.orc_vec_op.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u64p, u64p, u64p]
         _LIB.orc_qap_h.argtypes = [ctypes.c_int, ctypes.c_int, u64p, u64p, u64p, u64p, u64p, u64p, ctypes.c_int]
         _LIB.orc_ark_window.argtypes = [ctypes.c_uint64]
@@ -134,6 +135,20 @@ def ntt(curve_id, data, inverse=False, threads=1):
         raise ValueError("Domain size is too large")
     assert rc == 0
     return data
+
+
+def ntt_spot(curve_id, data, k, inverse=False, threads=1):
+    """output k of the transform of `data` (canonical (n, 4) limbs, NOT copied), straight from the definition: O(n)"""
+    data = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1, 4)
+    n = data.shape[0]
+    log_n = n.bit_length() - 1
+    assert 1 << log_n == n
+    out = np.zeros(4, dtype=np.uint64)
+    rc = lib().orc_ntt_spot(curve_id, _p(data), log_n, 1 if inverse else 0, k, _p(out), threads)
+    if rc == 2:
+        raise ValueError("Domain size is too large")
+    assert rc == 0
+    return out
 
 
 def vec_op(curve_id, op, a, b):

@@ -518,6 +518,35 @@ typedef Fp2<BlsFqTag> BlsG2K;
     else if ((curve) == 1 && (group) == 2) { CALL(BlsG2K, BlsFrTag) }   \
     else return 4;
 
+// ONE output of a transform straight from the definition (what src/bn254/polynomial.rs:535-571 computes
+// through ark-poly): X_k = sum_j a_j w^(jk), the inverse with w^-1 and the factor 1/n.  O(n) per output: the checker for sizes
+// where the full transform above is too slow to run inside a test (2^28, the largest BN254 domain)
+template <class FrTag>
+static int ntt_spot(const uint64_t* data, int log_n, int inverse, uint64_t k, int two_adicity, uint64_t gen, int threads, uint64_t* out) {
+    typedef Fp<FrTag> F;
+    if (log_n > two_adicity) return 2;
+    const size_t n = (size_t)1 << log_n;
+    F w = root_of_unity<FrTag>(log_n, two_adicity, gen);
+    if (inverse) w = w.inv();
+    uint64_t e[1] = {k & (n - 1)};
+    const F x = w.pow(e, 1);
+    const size_t len = n < 65536 ? n : 65536, chunks = n / len;
+    uint64_t le[1] = {len};
+    const F x_len = x.pow(le, 1);
+    std::vector<F> part(chunks);
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+    for (size_t c = 0; c < chunks; ++c) {
+        F acc = F::zero();
+        for (size_t j = len; j-- > 0;) acc = acc * x + F::from_canonical(data + 4 * (c * len + j));
+        part[c] = acc;
+    }
+    F total = F::zero();
+    for (size_t c = chunks; c-- > 0;) total = total * x_len + part[c];
+    if (inverse) total = total * F::from_u64(n).inv();
+    total.to_canonical(out);
+    return 0;
+}
+
 extern "C" {
 
 // curve: 0 = BN254, 1 = BLS12-381.  group: 1 = G1, 2 = G2.
@@ -562,6 +591,12 @@ int orc_point_add(int curve, int group, const uint64_t* a, const uint64_t* b, ui
     DISPATCH_GROUP(curve, group, CALL)
 #undef CALL
     return 0;
+}
+
+int orc_ntt_spot(int curve, const uint64_t* data, int log_n, int inverse, uint64_t k, uint64_t* out, int threads) {
+    if (curve == 0) return ntt_spot<BnFrTag>(data, log_n, inverse, k, 28, 5, threads, out);
+    if (curve == 1) return ntt_spot<BlsFrTag>(data, log_n, inverse, k, 32, 7, threads, out);
+    return 4;
 }
 
 int orc_ntt(int curve, uint64_t* data, int log_n, int inverse, int threads) {

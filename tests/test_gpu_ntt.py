@@ -156,6 +156,42 @@ def test_ntt_four_pass_size_2_25(gpu):
     assert N.limbs_to_ints(fwd[n // 2:n // 2 + 1])[0] == (total(a[0::2]) - total(a[1::2])) % r
 
 
+def test_ntt_largest_bn254_domain_2_28(gpu):
+    """2^28 is the largest domain BN254's Fr has (two-adicity 28; src/bn254/polynomial.rs:520,541 refuse anything above): four
+    passes of seven stages over 8 GiB, offsets beyond 32 bits everywhere.  The full CPU transform would take minutes, so single
+    outputs are checked against the definition (corc.ntt_spot, O(n) each; pinned against the full transform on the CPU),
+    forward and inverse, plus the round trip of the whole vector"""
+    import ctypes
+    cid, log_n = 0, 28
+    n = 1 << log_n
+    a = np.random.default_rng(28).integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    a[:, 3] >>= 3   # below 2^252 < r
+    d = ctypes.c_void_p()
+    N.check(gpu.zk_dev_alloc(a.nbytes, ctypes.byref(d)))
+    try:
+        N.check(gpu.zk_dev_upload(d, a.ctypes.data, a.nbytes))
+        N.check(gpu.zk_ntt_dev(cid, 0, log_n, d, None))
+        fwd = np.empty_like(a)
+        N.check(gpu.zk_dev_download(fwd.ctypes.data, d, a.nbytes))
+        N.check(gpu.zk_ntt_dev(cid, 1, log_n, d, None))
+        back = np.empty_like(a)
+        N.check(gpu.zk_dev_download(back.ctypes.data, d, a.nbytes))
+        assert np.array_equal(back, a)
+        del back
+        # the inverse transform of fresh data: a is read as a vector of evaluations
+        N.check(gpu.zk_dev_upload(d, a.ctypes.data, a.nbytes))
+        N.check(gpu.zk_ntt_dev(cid, 1, log_n, d, None))
+        inv = np.empty_like(a)
+        N.check(gpu.zk_dev_download(inv.ctypes.data, d, a.nbytes))
+    finally:
+        gpu.zk_dev_free(d)
+    # indices that touch every digit of the four passes: ends, halves, a tile boundary of each pass, arbitrary ones
+    for k in (0, 1, n // 2, n - 1, (1 << 21) + 1, (1 << 14) - 1, 0x9E3779B, 0x5A5A5A5):
+        assert (fwd[k] == corc.ntt_spot(cid, a, k, threads=16)).all(), k
+    for k in (0, n - 1, 0x3C6EF37, 0xDEADBEE):
+        assert (inv[k] == corc.ntt_spot(cid, a, k, inverse=True, threads=16)).all(), k
+
+
 def test_ntt_2_22_properties(gpu):
     """BASELINE config 3 size: round trip, linearity, and spot evaluation against Horner"""
     import ctypes

@@ -5,6 +5,7 @@ import json
 import os
 import random
 
+import numpy as np
 import pytest
 
 from oracle import corc, pyref as R
@@ -122,6 +123,17 @@ def test_cpp_restatement_matches_definitions(name, cid):
         assert corc.limbs_to_ints(corc.ntt(cid, corc.ints_to_limbs(v))) == R.ntt(v, n, cv)
         assert corc.limbs_to_ints(corc.ntt(cid, corc.ints_to_limbs(v), inverse=True)) == R.ntt(v, n, cv, inverse=True)
     assert R.dft_naive(v, n, cv) == R.ntt(v, n, cv)
+    # single outputs from the definition (the checker of the 2^28 GPU test): small sizes against the naive DFT, a size with
+    # several 65536-element chunks against the full transform of the restatement, forward and inverse, two thread counts
+    vl = corc.ints_to_limbs(v)
+    for k in (0, 1, n // 2, n - 1):
+        assert corc.limbs_to_ints(corc.ntt_spot(cid, vl, k).reshape(1, 4))[0] == R.dft_naive(v, n, cv)[k]
+        assert corc.limbs_to_ints(corc.ntt_spot(cid, vl, k, inverse=True).reshape(1, 4))[0] == R.ntt(v, n, cv, inverse=True)[k]
+    big = np.random.default_rng(5).integers(0, 1 << 62, size=(1 << 18, 4), dtype=np.uint64)
+    full, full_inv = corc.ntt(cid, big, threads=4), corc.ntt(cid, big, inverse=True, threads=4)
+    for k in (0, 3, 65536, (1 << 17) + 12345, (1 << 18) - 1):
+        assert (corc.ntt_spot(cid, big, k, threads=1 + (k & 3)) == full[k]).all()
+        assert (corc.ntt_spot(cid, big, k, inverse=True, threads=3) == full_inv[k]).all()
     a = [rnd.randrange(cv.r) for _ in range(10)]
     b = [rnd.randrange(cv.r) for _ in range(10)]
     for op, fn in (("mul", lambda x, y: x * y), ("add", lambda x, y: x + y), ("sub", lambda x, y: x - y)):
