@@ -34,6 +34,7 @@ def lib():
         _LIB.orc_point_add.argtypes = [ctypes.c_int, ctypes.c_int, u64p, u64p, u64p]
         _LIB.orc_ntt.argtypes = [ctypes.c_int, u64p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _LIB.orc_ntt_spot.argtypes = [ctypes.c_int, u64p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u64p, ctypes.c_int]
+        _LIB.orc_dot.argtypes = [ctypes.c_int, ctypes.c_uint64, u64p, u64p, u64p, ctypes.c_int]
         _LIB.orc_vec_op.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u64p, u64p, u64p]
         _LIB.orc_qap_h.argtypes = [ctypes.c_int, ctypes.c_int, u64p, u64p, u64p, u64p, u64p, u64p, ctypes.c_int]
         _LIB.orc_ark_window.argtypes = [ctypes.c_uint64]
@@ -149,6 +150,16 @@ def ntt_spot(curve_id, data, k, inverse=False, threads=1):
         raise ValueError("Domain size is too large")
     assert rc == 0
     return out
+
+
+def dot(curve_id, a, b, threads=1):
+    """sum a_i b_i mod r of two canonical (n, 4) limb arrays, as a Python int"""
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    assert a.shape == b.shape
+    out = np.zeros(4, dtype=np.uint64)
+    assert lib().orc_dot(curve_id, a.shape[0], _p(a), _p(b), _p(out), threads) == 0
+    return limbs_to_ints(out.reshape(1, 4))[0]
 
 
 def vec_op(curve_id, op, a, b):

@@ -605,6 +605,30 @@ int orc_ntt(int curve, uint64_t* data, int log_n, int inverse, int threads) {
     return 4;
 }
 
+// sum_i a_i b_i mod r: the discrete logarithm of MSM(a, b_i G), the closed-form expectation of SURVEY.md 8c(2) at sizes
+// where Python's big integers are too slow (2^26 pairs)
+int orc_dot(int curve, uint64_t n, const uint64_t* a, const uint64_t* b, uint64_t* out, int threads) {
+#define BODY(FR)                                                                                  \
+    {                                                                                             \
+        typedef Fp<FR> F;                                                                         \
+        const int T = threads > 0 ? threads : 1;                                                  \
+        std::vector<F> part(T, F::zero());                                                        \
+        _Pragma("omp parallel for schedule(static) num_threads(T)")                               \
+        for (int t = 0; t < T; ++t) {                                                             \
+            F acc = F::zero();                                                                    \
+            for (uint64_t i = n * t / T; i < n * (t + 1) / T; ++i)                                \
+                acc = acc + F::from_canonical(a + 4 * i) * F::from_canonical(b + 4 * i);          \
+            part[t] = acc;                                                                        \
+        }                                                                                         \
+        F total = F::zero();                                                                      \
+        for (int t = 0; t < T; ++t) total = total + part[t];                                      \
+        total.to_canonical(out);                                                                  \
+    }
+    if (curve == 0) BODY(BnFrTag) else if (curve == 1) BODY(BlsFrTag) else return 4;
+#undef BODY
+    return 0;
+}
+
 // op: 0 = mul, 1 = add, 2 = sub (element-wise over Fr)
 int orc_vec_op(int curve, int op, uint64_t n, const uint64_t* a, const uint64_t* b, uint64_t* out) {
 #define BODY(FR)                                                              \

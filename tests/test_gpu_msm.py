@@ -268,6 +268,44 @@ def test_msm_general_g1_at_the_split_scalar_limit(gpu, cid, extra):
     _known_dl_case(gpu, n, sc_limbs, sc_ints, cid, 1)
 
 
+@pytest.mark.parametrize("cid,grp", [(0, 1), (1, 2)])
+def test_msm_largest_plan_2_26(gpu, cid, grp):
+    """2^26 points is the largest plan the library accepts (one more is refused), here for the smallest and the largest point
+    type (all four groups pass; the other two are left out for the suite's running time) and both plan modes:
+    the general path with 16 plain windows (2^30 sort entries, no scalar split above 2^22 points) and the fixed-base path
+    (13 x 2^26 table rows: 56 GB for BN254 G1, 167 GB for BLS12-381 G2; 20-bit windows, fine bucket bits beside the entries) --
+    against the closed form (sum s_i k_i) G with the sum from the CPU oracle (corc.dot) and the final scalar multiplication
+    from the oracle as well"""
+    n = 1 << 26
+    r = (pyref.BN254 if cid == 0 else pyref.BLS12_381).r
+    PW = N.point_limbs(cid, grp)
+    sc = W.splitmix64(0x26A + grp, 4 * n).reshape(n, 4)
+    ks = W.splitmix64(0x26B + 8 * cid, 4 * n).reshape(n, 4)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)   # < 2^252 < r
+    ks[:, 3] &= np.uint64((1 << 60) - 1)
+    sc[:5] = N.ints_to_limbs([0, 1, r - 1, r - 2, 1 << 251])
+    gen = generator_limbs(gpu, cid, grp)
+    bases = np.zeros((n, PW), dtype=np.uint64)
+    N.check(gpu.zk_batch_mul(cid, grp, n, N.u64p(ks), N.u64p(gen), 1, N.u64p(bases)))
+    assert (bases[-64:] == corc.batch_mul(cid, grp, ks[-64:], gen)).all()       # spot check of the inputs themselves
+    dot = corc.dot(cid, sc, ks, threads=16)
+    exp = corc.batch_mul(cid, grp, N.ints_to_limbs([dot]), gen)[0]
+    del ks
+    h = N._u64(0)
+    assert gpu.zk_msm_plan_create(cid, grp, n + 1, bases.ctypes.data, 0, 0, 0, h) == N.ZK_ERR_ARG
+    for flags, layout in ((0, (16, 16)), (N.MSM_PRECOMPUTE, (20, 13))):
+        N.check(gpu.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, flags, 0, h))
+        try:
+            cb, nw = N._i(0), N._i(0)
+            N.check(gpu.zk_msm_plan_windows(h, cb, nw))
+            assert (cb.value, nw.value) == layout
+            out = np.zeros(PW, dtype=np.uint64)
+            N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, 0, 0, N.u64p(out), None))
+            assert (out == exp).all(), flags
+        finally:
+            N.check(gpu.zk_msm_plan_destroy(h))
+
+
 @pytest.mark.parametrize("cid,grp,log_n", [(0, 2, 16), (1, 1, 18), (1, 2, 15)])
 def test_msm_closed_form_other_groups(gpu, cid, grp, log_n):
     """BN254 G2 and the BLS12-381 twins at sizes where the closed form is the only cheap oracle"""

@@ -138,6 +138,10 @@ def test_cpp_restatement_matches_definitions(name, cid):
     b = [rnd.randrange(cv.r) for _ in range(10)]
     for op, fn in (("mul", lambda x, y: x * y), ("add", lambda x, y: x + y), ("sub", lambda x, y: x - y)):
         assert corc.limbs_to_ints(corc.vec_op(cid, op, corc.ints_to_limbs(a), corc.ints_to_limbs(b))) == [fn(x, y) % cv.r for x, y in zip(a, b)]
+    for threads in (1, 3):   # 10 pairs on 3 threads: ragged shares; values above r are reduced first
+        assert corc.dot(cid, corc.ints_to_limbs(a), corc.ints_to_limbs(b), threads) == sum(x * y for x, y in zip(a, b)) % cv.r
+    top = [(1 << 256) - 1 - i for i in range(5)]
+    assert corc.dot(cid, corc.ints_to_limbs(top), corc.ints_to_limbs(top[::-1]), 2) == sum(x * y for x, y in zip(top, top[::-1])) % cv.r
     for grp in (1, 2):
         g = R.Group(cv, grp)
         ks = [rnd.randrange(cv.r) for _ in range(20)] + [0, 1, cv.r - 1]
