@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--precompute", action="store_true", help="plan flag ZK_MSM_PRECOMPUTE (fixed-base table 2^(cw) P_i, shared buckets)")
     ap.add_argument("--plonk-log-n", type=int, default=18, help="gates (log2) of the PlonK prove in `extra`")
     ap.add_argument("--large-log-n", type=int, default=24, help="size (log2) of the large MSM reported in `extra` at every N")
+    ap.add_argument("--config5-log-n", type=int, default=23, help="constraints (log2) of the BLS12-381 prove of BASELINE configs[4] in "
+                    "`extra`, at every N; 0 skips it")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -260,6 +262,9 @@ def main():
     if not args.no_extra and world > 1:
         # the whole prove with its MSMs window-sharded over the ranks (BASELINE metric, second half); collective on all ranks
         sharded = prove_metric(torch, args, dev if args.backend == "nccl" else None, world)
+        if args.config5_log_n:
+            # BASELINE configs[4]: BLS12-381 at 2^23 constraints, G1 / G2 MSMs window-sharded over the ranks
+            sharded.update(prove_metric(torch, args, dev if args.backend == "nccl" else None, world, curve="BLS12_381", log_n=args.config5_log_n))
         sharded.update(large_msm_metric(lib, torch, args, dev, gather_dev, rank, world))
         if rank == 0:
             line["extra"] = sharded
@@ -365,6 +370,9 @@ def extra_metrics(lib, torch, dev, args, bases, d_scalars, expected):
 
     # (3) Groth16 prove on the benchmark chain circuit (BASELINE config 4), witness as host limb arrays
     out.update(prove_metric(torch, args, None, 1, with_cpu_baseline=not args.no_cpu_baseline))
+    if args.config5_log_n:
+        # BASELINE configs[4] in its single-GPU form (the 8-rank form is the same call at --gpus 8)
+        out.update(prove_metric(torch, args, None, 1, curve="BLS12_381", log_n=args.config5_log_n))
 
     # (4) PlonK prove on the same chain as gates, witness as a host limb array
     from zksnake_amd.arithmetization import Plonkish
@@ -567,18 +575,22 @@ def prove_cpu_baseline(g, A, B, C, w, threads):
     return secs, Proof(Apt, B2, Cpt).to_bytes()
 
 
-def prove_metric(torch, args, shard_device, world, with_cpu_baseline=False):
+def prove_metric(torch, args, shard_device, world, with_cpu_baseline=False, curve="BN254", log_n=None):
     """Groth16.prove on the benchmark chain circuit (benchmarks/benchmark_groth16.py:7-27 shape), pinned toxic waste and
     blinding so the proof is reproducible; timed region = prove() only, witness already on the host (benchmark_groth16.py:43-46).
-    With world > 1 the five MSMs are window-sharded over the ranks (Groth16.shard_over_ranks) and the time is the max over ranks."""
+    With world > 1 the five MSMs are window-sharded over the ranks (Groth16.shard_over_ranks) and the time is the max over ranks.
+    curve / log_n: BASELINE configs[3] by default (BN254, 2^20); configs[4] is BLS12-381 at 2^23 (reported at every N; the reference-call-shape
+    and CPU legs only run for the default)."""
     import hashlib
     import statistics
     from zksnake_amd.arithmetization import R1CS
     from zksnake_amd.groth16 import Groth16
-    pn = 1 << args.prove_log_n
-    r = constant.BN254_SCALAR_FIELD
+    headline_config = curve == "BN254" and log_n is None
+    log_n = args.prove_log_n if log_n is None else log_n
+    pn = 1 << log_n
+    r = W.scalar_field(curve)
     A, B, C, w, n_col = W.chain_circuit(pn, r)
-    g = Groth16(R1CS.from_triplets(A, B, C, pn, n_col, 2, "BN254"), "BN254")
+    g = Groth16(R1CS.from_triplets(A, B, C, pn, n_col, 2, curve), curve)
     g._toxic = tuple(W.field_stream(W.SEED_PROVE, 5, r)[1])
     g._blinding = tuple(W.field_stream(W.SEED_PROVE, 2, r, offset=5)[1])
     if world > 1:
@@ -619,16 +631,16 @@ def prove_metric(torch, args, shard_device, world, with_cpu_baseline=False):
     gpath = os.path.join(ROOT, "tests", "golden", "groth16_vectors.json")
     if os.path.exists(gpath):
         with open(gpath) as f:
-            gold = json.load(f).get("BN254", {}).get(str(args.prove_log_n))
+            gold = json.load(f).get(curve, {}).get(str(log_n))
         if gold is not None:
             res["matches_committed_closed_form"] = bool(proof.to_bytes().hex() == gold["proof_hex"])
             if not res["matches_committed_closed_form"]:
                 raise SystemExit("Groth16 proof bytes differ from the committed closed-form proof (tests/golden/groth16_vectors.json)")
-    if world == 1:
+    if world == 1 and headline_config:
         # (4 x 96 + 160 + 9 x 64 + 2 x 96 + 3 x 32) B per constraint over the whole prove
         gb = PROVE_BYTES_PER_CONSTRAINT * pn / 1e9
         from tools.fingerprint import load_traffic
-        p_traffic, p_src = load_traffic("prove_traffic.json", "prove") if args.prove_log_n == 20 else (None, None)
+        p_traffic, p_src = load_traffic("prove_traffic.json", "prove") if log_n == 20 else (None, None)
         res["roofline"] = {"bound": "hbm", "achieved": round(gb / (med * 1e-3), 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": round(gb / (med * 1e-3) / HBM_PEAK_GBPS, 5), "algorithmic_GB": round(gb, 3), "traffic": p_traffic,
                            "traffic_source": p_src,
@@ -664,7 +676,7 @@ def prove_metric(torch, args, shard_device, world, with_cpu_baseline=False):
         secs, cpu_bytes = prove_cpu_baseline(g, A, B, C, w, 1)
         if cpu_bytes != proof.to_bytes():
             raise SystemExit("the CPU restatement and the GPU prover disagree on the proof bytes")
-        sample = (f"the same proof at the full 2^{args.prove_log_n} constraints (same key, witness and blinding): QAP quotient (radix-2 NTTs: "
+        sample = (f"the same proof at the full 2^{log_n} constraints (same key, witness and blinding): QAP quotient (radix-2 NTTs: "
                   "three of size n, three of size 2n) + four G1 and one G2 ark-style Pippenger MSMs, oracle/zk_oracle.cpp; its proof "
                   "bytes equal the GPU prover's")
         res["cpu_baseline"] = {"value": round(secs * 1e3, 1), "unit": "ms", "cores": 1, "kind": "port",
@@ -691,7 +703,10 @@ def prove_metric(torch, args, shard_device, world, with_cpu_baseline=False):
             "speedup_bound_at_infinite_ranks": round((replicated + world * sharded) / replicated, 2),
             "note": "projection from this run's split, not a measurement: the MSM part also has per-rank fixed costs (bucket reduction, "
                     "host tail) that do not shrink with the window count"}
-    key = f"groth16_prove_bn254_2^{args.prove_log_n}" + (f"_window_sharded_x{world}" if world > 1 else "")
+    key = f"groth16_prove_{curve.lower()}_2^{log_n}" + (f"_window_sharded_x{world}" if world > 1 else "")
+    del g
+    gc.unfreeze()
+    gc.collect()
     return {key: res}
 
 
