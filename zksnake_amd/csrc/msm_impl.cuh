@@ -169,7 +169,12 @@ struct MsmPlan : MsmPlanBase {
         uint32_t* parts = nullptr;  // partial row / column sums of the two-step strided sums
         uint32_t *tmp_ref = nullptr, *bin_start = nullptr, *slice_sums = nullptr, *bin_tot = nullptr;  // two-level sort
         uint8_t* tmp_fine = nullptr;  // fine bucket bits of the level-A entries when the reference needs all 31 bits
-        hipEvent_t ev_begin = nullptr, ev_acc0 = nullptr, ev_accs = nullptr, ev_acc1 = nullptr, ev_done = nullptr;
+        // A recorded event costs ~3 us of idle GPU between two kernels (tools/event_gap_probe.hip), so a run records only the four
+        // that order work or bound a stage: ev_start (plan), ev_acc0 = sorted (also the lender's "sorted_ready"), ev_acc1 =
+        // accumulated (the gate of the next plan's accumulate kernel), ev_end (plan); ev_accs only when the accumulate kernel
+        // waits for something after the sort (a gate, or the second half of a two-step enqueue)
+        hipEvent_t ev_acc0 = nullptr, ev_accs = nullptr, ev_acc1 = nullptr;
+        bool acc_from_accs = false;
         hipEvent_t ev_release = nullptr;  // recorded by a borrower of this run's sort (enqueue_shared) after its last read
         bool lent = false;
         uint32_t seg_len = 0;
@@ -192,7 +197,7 @@ struct MsmPlan : MsmPlanBase {
     uint32_t* d_scalars = nullptr;
     void* d_dig = nullptr;  // windows x (n + 8) digits, uint16_t (c <= 16) or uint32_t
     uint32_t* h_final = nullptr;  // pinned: (S, T) per weighted-sum block
-    hipEvent_t ev_start = nullptr, ev_digits = nullptr, ev_end = nullptr;
+    hipEvent_t ev_start = nullptr, ev_end = nullptr;
 
     ~MsmPlan() override {
         // blocks go back to the caching allocator, which (unlike hipFree) does not wait for the device: make sure no run of
@@ -203,7 +208,7 @@ struct MsmPlan : MsmPlanBase {
                         d_scalars, d_dig};
         for (void* q : bufs) dev_free_cached(q);
         pinned_free_cached(h_final);
-        for (hipEvent_t e : {ws.ev_begin, ws.ev_acc0, ws.ev_accs, ws.ev_acc1, ws.ev_done, ws.ev_release, ev_start, ev_digits, ev_end}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ws.ev_acc0, ws.ev_accs, ws.ev_acc1, ws.ev_release, ev_start, ev_end}) if (e) (void)hipEventDestroy(e);
         stream_release((create_flags & ZK_MSM_HIGH_PRIORITY) != 0, own_stream);
     }
 
@@ -294,7 +299,8 @@ struct MsmPlan : MsmPlanBase {
         const uint64_t max_sets = pre ? 1ull : (uint64_t)pw_count;
         ZK_HIP_RC(pinned_alloc_cached((void**)&h_final, (size_t)max_sets * (bpr + bpc) * 2 * XW * 4));
         mark("scalars/digits/pinned");
-        for (hipEvent_t* e : {&ev_start, &ev_digits, &ev_end}) ZK_HIP(hipEventCreate(e));
+        ZK_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableSystemFence));   // timing only: nothing synchronises with it
+        ZK_HIP(hipEventCreate(&ev_end));
         {
             const uint64_t keys = max_sets * B;
             // a window-range run picks its own (shorter) segments: at most SEG_TARGET_LANES of them, or entries / 8
@@ -322,7 +328,7 @@ struct MsmPlan : MsmPlanBase {
             ZK_ALLOC(&ws.rows, max_sets * (R + C) * XW * 4);
             if (sum_part_len() >= 2) ZK_ALLOC(&ws.parts, max_sets * 2 * (uint64_t)(B / sum_part_len()) * XW * 4);
             ZK_ALLOC(&ws.fin, max_sets * (bpr + bpc) * 2 * XW * 4);
-            for (hipEvent_t* e : {&ws.ev_begin, &ws.ev_acc0, &ws.ev_accs, &ws.ev_acc1, &ws.ev_done, &ws.ev_release}) ZK_HIP(hipEventCreate(e));
+            for (hipEvent_t* e : {&ws.ev_acc0, &ws.ev_accs, &ws.ev_acc1, &ws.ev_release}) ZK_HIP(hipEventCreate(e));
         }
         mark("workspace + events");
         // LDS above 64 KiB needs the opt-in
@@ -556,7 +562,6 @@ struct MsmPlan : MsmPlanBase {
         int rc;
         const uint32_t seg_len = borrowed ? borrowed->seg_len : (phase == 2 ? l.seg_len : pick_seg_len((uint64_t)l.w_count * m));
         l.seg_len = seg_len;
-        if (phase != 2) ZK_HIP(hipEventRecord(l.ev_begin, st));
         const uint32_t *p_sorted = l.sorted, *p_bstart = l.bstart, *p_sstart = l.sstart, *p_big_list = l.big_list, *p_big_count = l.big_count;
         if (phase == 2) {
             // sorted in phase 1
@@ -570,12 +575,11 @@ struct MsmPlan : MsmPlanBase {
         if (phase != 2) ZK_HIP(hipEventRecord(l.ev_acc0, st));
         if (phase == 1) return ZK_OK;
         if (gate) ZK_HIP(hipStreamWaitEvent(st, gate, 0));
-        ZK_HIP(hipEventRecord(l.ev_accs, st));
+        l.acc_from_accs = gate != nullptr || phase == 2;
+        if (l.acc_from_accs) ZK_HIP(hipEventRecord(l.ev_accs, st));
         if ((rc = stage_accumulate(m, seg_len, st, p_sorted, p_bstart, p_sstart, p_big_list, p_big_count))) return rc;
         if (borrowed) ZK_HIP(hipEventRecord(borrowed->release, st));  // the lender's buffers are no longer read
-        if ((rc = stage_reduce(st))) return rc;
-        ZK_HIP(hipEventRecord(l.ev_done, st));
-        return ZK_OK;
+        return stage_reduce(st);   // the caller records ev_end
     }
 
     int set_option(const char* name, int64_t value) override {
@@ -682,7 +686,6 @@ struct MsmPlan : MsmPlanBase {
                                          reinterpret_cast<uint32_t*>(dig_base), ws.big_count);
             else hipLaunchKernelGGL((digits_kernel<FrP, uint16_t>), dim3((m + 255) / 256), dim3(256), 0, st, sc, m, dstride, c, w_first, w_count, bias,
                                     reinterpret_cast<uint16_t*>(dig_base), ws.big_count);
-            ZK_HIP(hipEventRecord(ev_digits, st));
             ws.w_first = w_first;
             ws.w_count = w_count;
             ws.groups = pre ? 1u : (uint32_t)w_count;
@@ -735,7 +738,6 @@ struct MsmPlan : MsmPlanBase {
         }
         q_first = ex.w_first; q_count = ex.w_count; q_m = ex.m; q_stream = st;
         ZK_HIP(hipEventRecord(ev_start, st));
-        ZK_HIP(hipEventRecord(ev_digits, st));
         ws.w_first = ex.w_first;
         ws.w_count = ex.w_count;
         ws.groups = ex.groups;
@@ -753,8 +755,10 @@ struct MsmPlan : MsmPlanBase {
         q_pending = false;
         typedef typename G::HostF HF;  // 64-bit-limb host arithmetic for the sequential tail (host64.cuh)
         XYZZ<HF> total = xyzz_inf<HF>();
+        std::chrono::steady_clock::time_point tail_t0;
         if (q_m > 0) {
             ZK_HIP(hipEventSynchronize(ev_end));
+            tail_t0 = std::chrono::steady_clock::now();
             // 8. host tail.  Per bucket set, with row blocks (S_k, T_k), column blocks (S'_k, T'_k), C = 2^lc, WS_BLOCK = 2^7:
             //        W = 2^(lc+7) X_R + 2^lc sum S_k + 2^7 X_C + (sum S'_k + sum T_k),   X = sum_k k T_k  (k = 1 at most)
             //    general mode: total = sum_w 2^(c w) W_w by Horner from the top window down; the factors ride along the c
@@ -806,22 +810,20 @@ struct MsmPlan : MsmPlanBase {
             }
             if (!pre) for (int k = 0; k < c * q_first; ++k) total = xyzz_dbl<HF>(total);
             float sort_ms = 0, acc_ms = 0, red_ms = 0, t = 0;
-            if (hipEventElapsedTime(&t, ws.ev_begin, ws.ev_acc0) == hipSuccess) sort_ms += t;
-            if (hipEventElapsedTime(&t, ws.ev_accs, ws.ev_acc1) == hipSuccess) acc_ms += t;
-            if (hipEventElapsedTime(&t, ws.ev_acc1, ws.ev_done) == hipSuccess) red_ms += t;
-            if (hipEventElapsedTime(&t, ev_start, ev_digits) == hipSuccess) sort_ms += t;
+            if (hipEventElapsedTime(&t, ev_start, ws.ev_acc0) == hipSuccess) sort_ms += t;
+            if (hipEventElapsedTime(&t, ws.acc_from_accs ? ws.ev_accs : ws.ev_acc0, ws.ev_acc1) == hipSuccess) acc_ms += t;
+            if (hipEventElapsedTime(&t, ws.ev_acc1, ev_end) == hipSuccess) red_ms += t;
             timings[0] = sort_ms;   // digits + sort
             timings[1] = acc_ms;    // accumulate kernel
             timings[2] = red_ms;    // combine + reduction + D2H
         }
         HF::affine_to_canonical(xyzz_to_affine<HF>(total), out);
         if (q_m > 0) {
+            // the tail runs on the host: its time comes from the host's clock (an event recorded and awaited here would put a
+            // GPU round trip of 10-20 us on the critical path of every MSM just to time it)
+            timings[3] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tail_t0).count();
             float t = 0;
-            ZK_HIP(hipEventRecord(ev_digits, q_stream));  // reuse as "host tail done" marker
-            ZK_HIP(hipEventSynchronize(ev_digits));
-            (void)hipEventElapsedTime(&timings[3], ev_end, ev_digits);
-            (void)hipEventElapsedTime(&timings[4], ev_start, ev_digits);
-            (void)t;
+            timings[4] = hipEventElapsedTime(&t, ev_start, ev_end) == hipSuccess ? t + timings[3] : 0.0f;
         }
         return ZK_OK;
     }
