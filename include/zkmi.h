@@ -255,6 +255,9 @@ int zk_msm_plan_timings(uint64_t handle, float* ms, int cap);
  *   "sum_one_step"      1 = row / column sums of the bucket reduction in one launch                 ZKMI_SUM_ONE_STEP
  *   "lanes_per_output"  lanes per row / column sum of the one-step form (0 = automatic, 2 .. 64)    ZKMI_LPO
  *   "two_level_sort"    0 = one-level / bucket-range sorts only (windows <= 16 bits)                ZKMI_NO_TWO_LEVEL
+ *   "priority_steps"    0 = the waves of the accumulate kernel keep one issue priority throughout   ZKMI_NO_PRIO_STEPS
+ *                       (default 1: they step it down near the end of their segment, which keeps the waves of a SIMD together
+ *                       when the kernel has the chip to itself; applies to zk_msm_plan_run / zk_msm_plan_enqueue only)
  * Results never depend on them.  ZK_ERR_ARG for unknown names (including the creation-time options ZKMI_SORT_WGS,
  * ZKMI_FINE_LOG, ZKMI_NO_GLV, ZKMI_PRE_C), for values the plan cannot honour and while a run is in flight. */
 int zk_msm_plan_set_option(uint64_t handle, const char* name, int64_t value);

@@ -577,7 +577,8 @@ def test_shared_sort_between_g1_and_g2_plans(gpu, flags, n):
 def test_plan_options_switch_paths_in_process(gpu, flags):
     """zk_msm_plan_set_option flips the tuning knobs of ONE live plan (they used to be process-wide environment latches, and
     this test had to run a child process): the chunked one-level sort (which otherwise only serves n > 2^24), one-step
-    row / column sums, other lane counts -- every combination gives the oracle's point; bad names and values are refused"""
+    row / column sums, other lane counts, the accumulate kernel with and without its priority steps -- every combination gives
+    the oracle's point; bad names and values are refused"""
     cid, grp, n = 0, 1, 1 << 19
     bases, r = _bases_from_library(gpu, cid, grp, n, 0x0F710)
     sc = W.splitmix64(0x5CA1A, 4 * n).reshape(n, 4)
@@ -596,7 +597,8 @@ def test_plan_options_switch_paths_in_process(gpu, flags):
         base, _ = run()
         assert (base == exp).all()
         for name, value in ((b"two_level_sort", 0), (b"sum_one_step", 1), (b"lanes_per_output", 16), (b"segment_lanes", 65536),
-                            (b"two_level_sort", 1), (b"sum_one_step", 0), (b"lanes_per_output", 0)):
+                            (b"priority_steps", 0), (b"two_level_sort", 1), (b"sum_one_step", 0), (b"lanes_per_output", 0),
+                            (b"priority_steps", 1)):
             N.check(gpu.zk_msm_plan_set_option(h, name, value))
             out, _ = run()
             assert (out == exp).all(), (name, value)

@@ -10,8 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SOURCES = {
     # the accumulate kernel and everything inlined into it
-    "msm": ("zksnake_amd/csrc/msm_impl.cuh", "zksnake_amd/csrc/curve.cuh", "zksnake_amd/csrc/field.cuh",
-            "zksnake_amd/csrc/field_params.h", "zksnake_amd/csrc/msm_plan.h", "zksnake_amd/csrc/pair.cuh"),
+    "msm": ("zksnake_amd/csrc/msm_impl.cuh", "zksnake_amd/csrc/msm_accumulate.cuh", "zksnake_amd/csrc/msm_common.cuh",
+            "zksnake_amd/csrc/msm_sort.cuh", "zksnake_amd/csrc/msm_reduce.cuh", "zksnake_amd/csrc/curve.cuh",
+            "zksnake_amd/csrc/field.cuh", "zksnake_amd/csrc/field_params.h", "zksnake_amd/csrc/msm_plan.h",
+            "zksnake_amd/csrc/pair.cuh"),
 }
 SOURCES["prove"] = SOURCES["msm"] + ("zksnake_amd/csrc/ntt.hip", "zksnake_amd/csrc/fr_mem.cuh", "zksnake_amd/groth16/protocol.py",
                                       "zksnake_amd/groth16/qap.py")

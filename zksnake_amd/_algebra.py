@@ -107,12 +107,14 @@ class PointArray:
                 N.check(lib.zk_point_decompress(curve_id, group, N.u8p(raw[i * nb:(i + 1) * nb]), N.u64p(limbs[i])))
         return cls(curve_id, group, limbs)
 
-    def plan(self, slot=0, precompute=False, high_priority=False, window_bits=0):
+    def plan(self, slot=0, precompute=False, high_priority=False, window_bits=0, concurrent=False):
         """device-resident bases + workspace (created on first use).  A second slot gives an independent
         workspace so two MSMs over the same key (tau_1 with u and with v) can be in flight together.
         precompute=True builds the fixed-base table 2^(c w) P_i (ZK_MSM_PRECOMPUTE): right for proving keys,
         which are reused by every proof.  high_priority puts the plan's own stream at the top priority level;
-        window_bits 0 = the library's choice for len(self) points."""
+        window_bits 0 = the library's choice for len(self) points.  concurrent=True says that the plan runs beside other plans
+        (a prover's pipelines): a NEW plan then keeps one issue priority in its accumulate kernel (plan option "priority_steps" = 0;
+        the steps pay only when the kernel has the GPU to itself, include/zkmi.h)."""
         key = (slot, bool(precompute))
         # clones share the first plan's bases, so all plans of a mode have one window layout: a call that asks for another
         # width, or comes after window_range changed, drops them and builds anew instead of silently handing back a plan
@@ -141,6 +143,8 @@ class PointArray:
                 else:
                     N.check(lib.zk_msm_plan_create(self.curve_id, self.group, len(self), self.limbs.ctypes.data, 0, flags,
                                                    window_bits, h))
+            if concurrent:
+                N.check(lib.zk_msm_plan_set_option(h.value, b"priority_steps", 0))
             self._plans[key] = h.value
         return self._plans[key]
 

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256, AccumulateWaves<G>::PER_SIMD) void accumulate_
                                                          const uint32_t* __restrict__ sorted,
                                                          const uint32_t* __restrict__ bucket_start,
                                                          const uint32_t* __restrict__ run_start, uint32_t n_keys,
-                                                         uint32_t seg_len, uint32_t* __restrict__ partials,
+                                                         uint32_t seg_len, uint32_t prio_steps, uint32_t* __restrict__ partials,
                                                          uint32_t* __restrict__ buckets) {
     typedef typename G::F F;
     constexpr int AW = 2 * F::LIMBS;
@@ -47,7 +47,24 @@ __global__ __launch_bounds__(256, AccumulateWaves<G>::PER_SIMD) void accumulate_
     uint32_t key = lo;
     uint32_t next = bucket_start[key + 1];
     XYZZ<F> acc = xyzz_inf<F>();
+    // The SIMD issues from its oldest wave first.  Left alone, the four waves that share a SIMD finish one after the other -- at 28,
+    // 50, 75 and 100 % of the kernel's time -- and the last of them runs alone, at the issue rate of a lone wave, for the last quarter
+    // (tools/acc_tail_probe.hip: 90 ps per addition against 71 with eight-entry segments).  So every wave lowers its own issue priority
+    // as it passes 75, 90 and 97 % of its segment: the waves of a SIMD wait for each other there, all four stay resident to the end
+    // and only the last 3 % of the work runs unsynchronised.  Only when the kernel has the chip to itself (prio_steps: a plain run of
+    // a plan): inside a proof the slots a finished wave leaves are taken by the kernels of the other plans at once, the steps gain
+    // nothing there and starve those kernels (measured).  The step counter is the same in every lane, but only a scalar makes the
+    // branch around s_setprio a scalar branch: under a lane mask the compiler lets the (scalar) instruction run whatever the mask
+    // is, i.e. in every iteration.
+    const uint32_t q1 = seg_len - seg_len / 4, q2 = seg_len - seg_len / 10, q3 = seg_len - (seg_len + 31) / 32;
+    if (prio_steps) __builtin_amdgcn_s_setprio(3);
     for (uint32_t e = begin; e < end; ++e) {
+        if (prio_steps) {
+            const uint32_t step = __builtin_amdgcn_readfirstlane(e - begin);
+            if (step == q1) __builtin_amdgcn_s_setprio(2);
+            else if (step == q2) __builtin_amdgcn_s_setprio(1);
+            else if (step == q3) __builtin_amdgcn_s_setprio(0);
+        }
         if (e == next) {
             // the bucket ends inside this segment: flush its run, move to the next non-empty bucket
             xyzz_relaxed_finish<F>(acc);

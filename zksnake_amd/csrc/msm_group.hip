@@ -20,7 +20,7 @@
 namespace zkmi {
 
 #if ZK_PART == 1
-template __global__ void accumulate_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*);
+template __global__ void accumulate_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t*);
 template __global__ void bases_to_mont_kernel<ZK_GROUP>(const uint32_t*, uint64_t, uint32_t*, int);
 #elif ZK_PART == 2
 template __global__ void combine_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*);

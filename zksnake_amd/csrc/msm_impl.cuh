@@ -46,7 +46,7 @@ namespace zkmi {
 
 #if defined(ZK_GROUP) && (!defined(ZK_PART) || ZK_PART == 0)
 // the plan's translation unit does not instantiate the heavy kernels (see msm_group.hip)
-extern template __global__ void accumulate_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*);
+extern template __global__ void accumulate_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t*);
 extern template __global__ void bases_to_mont_kernel<ZK_GROUP>(const uint32_t*, uint64_t, uint32_t*, int);
 extern template __global__ void combine_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*);
 extern template __global__ void strided_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t*, SumJob, SumJob, uint32_t);
@@ -499,11 +499,11 @@ struct MsmPlan : MsmPlanBase {
 
     // stage 5: the dominant kernel; stage 6: buckets whose entries span several segments (three tiers, one launch)
     int stage_accumulate(uint32_t m, uint32_t seg_len, hipStream_t st, const uint32_t* p_sorted, const uint32_t* p_bstart,
-                         const uint32_t* p_sstart, const uint32_t* p_big_list, const uint32_t* p_big_count) {
+                         const uint32_t* p_sstart, const uint32_t* p_big_list, const uint32_t* p_big_count, bool prio_steps) {
         Work& l = ws;
         const uint32_t n_keys = l.groups * B;
         const uint64_t lanes_needed = ((uint64_t)l.w_count * m + seg_len - 1) / seg_len;
-        hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((lanes_needed + 255) / 256)), dim3(256), 0, st, d_bases, p_sorted, p_bstart, p_sstart, n_keys, seg_len, l.partials, l.buckets);
+        hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((lanes_needed + 255) / 256)), dim3(256), 0, st, d_bases, p_sorted, p_bstart, p_sstart, n_keys, seg_len, prio_steps ? 1u : 0u, l.partials, l.buckets);
         ZK_HIP(hipEventRecord(l.ev_acc1, st));
         const uint32_t small_blocks = (2 * n_keys + COMBINE_THREADS - 1) / COMBINE_THREADS;
         hipLaunchKernelGGL(combine_kernel<G>, dim3(small_blocks + COMBINE_WAVE_BLOCKS + COMBINE_BIG_BLOCKS), dim3(COMBINE_THREADS), 0, st,
@@ -577,7 +577,10 @@ struct MsmPlan : MsmPlanBase {
         if (gate) ZK_HIP(hipStreamWaitEvent(st, gate, 0));
         l.acc_from_accs = gate != nullptr || phase == 2;
         if (l.acc_from_accs) ZK_HIP(hipEventRecord(l.ev_accs, st));
-        if ((rc = stage_accumulate(m, seg_len, st, p_sorted, p_bstart, p_sstart, p_big_list, p_big_count))) return rc;
+        // priority steps (msm_accumulate.cuh) for a run in one piece that waits for nothing: the two-step, gated and shared forms
+        // are what a prover uses to overlap several plans
+        const bool prio_steps = opt.priority_steps && phase == 0 && !gate && !borrowed;
+        if ((rc = stage_accumulate(m, seg_len, st, p_sorted, p_bstart, p_sstart, p_big_list, p_big_count, prio_steps))) return rc;
         if (borrowed) ZK_HIP(hipEventRecord(borrowed->release, st));  // the lender's buffers are no longer read
         return stage_reduce(st);   // the caller records ev_end
     }
@@ -595,6 +598,8 @@ struct MsmPlan : MsmPlanBase {
         } else if (!strcmp(name, "lanes_per_output")) {
             if (value != 0 && (value < 2 || value > 64 || (value & (value - 1)))) return fail(ZK_ERR_ARG, "lanes_per_output: 0 or a power of two in [2, 64]");
             opt.lanes_per_output = (uint32_t)value;
+        } else if (!strcmp(name, "priority_steps")) {
+            opt.priority_steps = value != 0;
         } else if (!strcmp(name, "two_level_sort")) {
             if (value && !ws.tmp_ref) return fail(ZK_ERR_ARG, "the plan was created without the buffers of the two-level sort");
             if (!value && wide) return fail(ZK_ERR_ARG, "windows wider than 16 bits exist in the two-level sort only");

@@ -111,6 +111,8 @@ struct MsmOptions {
     bool sum_one_step = false;               // ZKMI_SUM_ONE_STEP: row / column sums in one launch whatever the bucket count
     uint32_t lanes_per_output = 0;           // ZKMI_LPO: lanes per row / column sum of the one-step form (0 = by output count)
     bool two_level_sort = true;              // ZKMI_NO_TWO_LEVEL clears it: one-level / bucket-range sorts only (c <= 16)
+    bool priority_steps = true;              // ZKMI_NO_PRIO_STEPS clears it: accumulate waves step their issue priority down near the
+                                             // end of their segment (plain runs only, msm_accumulate.cuh)
     // layout (creation time only)
     uint32_t sort_workgroups = 256;          // ZKMI_SORT_WGS: bucket-range sort workgroups over all windows
     int fine_log = 0;                        // ZKMI_FINE_LOG: fine bucket bits of the two-level sort (0 = automatic)
@@ -122,6 +124,7 @@ struct MsmOptions {
         o.sum_one_step = getenv("ZKMI_SUM_ONE_STEP") != nullptr;
         if (const char* e = getenv("ZKMI_LPO")) o.lanes_per_output = (uint32_t)atoi(e);
         o.two_level_sort = getenv("ZKMI_NO_TWO_LEVEL") == nullptr;
+        o.priority_steps = getenv("ZKMI_NO_PRIO_STEPS") == nullptr;
         if (const char* e = getenv("ZKMI_SORT_WGS")) o.sort_workgroups = (uint32_t)atoi(e);
         if (const char* e = getenv("ZKMI_FINE_LOG")) o.fine_log = atoi(e);
         o.trace_init = getenv("ZKMI_TRACE_INIT") != nullptr;
@@ -132,7 +135,7 @@ struct MsmOptions {
 struct MsmPlanBase {
     virtual ~MsmPlanBase() {}
     MsmOptions opt = MsmOptions::from_env();
-    // name: "segment_lanes", "sum_one_step", "lanes_per_output", "two_level_sort"; ZK_ERR_ARG for anything else, for a value
+    // name: "segment_lanes", "sum_one_step", "lanes_per_output", "two_level_sort", "priority_steps"; ZK_ERR_ARG for anything else, for a value
     // the plan cannot honour (two-level sort without its buffers, one-level sort for windows wider than 16 bits) and while a
     // run is in flight
     virtual int set_option(const char* name, int64_t value) = 0;

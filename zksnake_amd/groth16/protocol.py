@@ -149,7 +149,7 @@ class Groth16:
             if rng[1] == 0:
                 return None
             arr.window_range = rng
-        return arr.plan(slot, precompute=self.precompute_keys, high_priority=high_priority)
+        return arr.plan(slot, precompute=self.precompute_keys, high_priority=high_priority, concurrent=True)
 
     def prepare_prover(self):
         """build what the first prove() would otherwise build: the fixed-base MSM plans of the proving key and the QAP's
@@ -215,7 +215,7 @@ class Groth16:
             if cnt == 0:
                 return arr, None
             arr.window_range = (first, cnt)
-        handle = arr.plan(slot, precompute=self.precompute_keys, high_priority=high_priority)
+        handle = arr.plan(slot, precompute=self.precompute_keys, high_priority=high_priority, concurrent=True)
         if wait_event is not None:
             N.check(lib.zk_msm_plan_wait_event(handle, wait_event))   # the scalars are still being produced on another stream
         if share_sort_of is not None and count == len(arr) and not os.environ.get("ZKMI_NO_SHARED_SORT"):

@@ -61,7 +61,7 @@ class Plonk:
             pk.tau_g1 = PointArray(cid, 1, _points_to_limbs(pk.tau_g1, cid, 1))
         # tau_g1 holds ~4n points but a commitment multiplies n + 2 .. 3n + 5 of them: below 2^20 gates the 16-bit windows
         # win (the wider windows the library would pick for the table's size pay only from ~2^20 scalars per MSM)
-        return pk.tau_g1.plan(slot, precompute=True, window_bits=16 if pk.n < (1 << 20) else 0)
+        return pk.tau_g1.plan(slot, precompute=True, window_bits=16 if pk.n < (1 << 20) else 0, concurrent=True)
 
     def _commit_many(self, jobs, meanwhile=None):
         """jobs: [(device vector, count, offset)] -> commitments; the MSMs of one round run concurrently on their plans'
