@@ -35,7 +35,8 @@ def per_kernel(path, counter):
 
 def first(pattern):
     hits = glob.glob(pattern, recursive=True)
-    return hits[0] if hits else None
+    # gpurun merges every collection into the same directories (the files carry the profiler's process id): take the newest
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 def main():
