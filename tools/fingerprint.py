@@ -13,7 +13,7 @@ SOURCES = {
     "msm": ("zksnake_amd/csrc/msm_impl.cuh", "zksnake_amd/csrc/msm_accumulate.cuh", "zksnake_amd/csrc/msm_common.cuh",
             "zksnake_amd/csrc/msm_sort.cuh", "zksnake_amd/csrc/msm_reduce.cuh", "zksnake_amd/csrc/curve.cuh",
             "zksnake_amd/csrc/field.cuh", "zksnake_amd/csrc/field_params.h", "zksnake_amd/csrc/msm_plan.h",
-            "zksnake_amd/csrc/pair.cuh"),
+            "zksnake_amd/csrc/pair.cuh", "zksnake_amd/csrc/hipcc_noreassoc.sh", "zksnake_amd/csrc/Makefile"),
 }
 SOURCES["prove"] = SOURCES["msm"] + ("zksnake_amd/csrc/ntt.hip", "zksnake_amd/csrc/fr_mem.cuh", "zksnake_amd/groth16/protocol.py",
                                       "zksnake_amd/groth16/qap.py")
