@@ -7,7 +7,7 @@
 # driver has no switch for a single pass, so the device half goes through its stages by hand:
 #   clang (HIP -> unoptimised device bitcode, device libraries linked in) -> opt (the pipeline `opt -O3` prints, minus
 #   `reassociate`) -> llc -> lld (code object) -> clang-offload-bundler -> clang host compile with the bundle embedded.
-# usage: hipcc_noreassoc.sh <out.o> <source.hip> [compiler flags...]     (ARCH, LLVM_BIN from the environment)
+# usage: hipcc_noreassoc.sh <out.o> <source.hip> [compiler flags...]     (ARCH, LLVM_BIN, LLCFLAGS from the environment)
 set -euo pipefail
 OUT=$1; SRC=$2; shift 2
 ARCH=${ARCH:-gfx950}
@@ -20,7 +20,8 @@ PIPE=$( ("$LLVM/opt" -O3 -print-pipeline-passes "$TMP/dev.bc" -o /dev/null 2>/de
 case "$PIPE" in *reassociate,*) ;; *) echo "hipcc_noreassoc.sh: no reassociate pass in the O3 pipeline of this toolchain" >&2; exit 1;; esac
 PIPE=${PIPE//reassociate,/}
 "$LLVM/opt" -mtriple=amdgcn-amd-amdhsa -mcpu=$ARCH -amdgpu-internalize-symbols -passes="$PIPE" "$TMP/dev.bc" -o "$TMP/dev.opt.bc"
-"$LLVM/llc" -mtriple=amdgcn-amd-amdhsa -mcpu=$ARCH -O3 -relocation-model=pic -filetype=obj "$TMP/dev.opt.bc" -o "$TMP/dev.o"
+# LLCFLAGS: extra code-generation options of one translation unit (the Makefile passes a scheduling strategy for some)
+"$LLVM/llc" -mtriple=amdgcn-amd-amdhsa -mcpu=$ARCH -O3 -relocation-model=pic -filetype=obj ${LLCFLAGS:-} "$TMP/dev.opt.bc" -o "$TMP/dev.o"
 "$LLVM/lld" -flavor gnu -m elf64_amdgpu --no-undefined -shared -o "$TMP/dev.hsaco" "$TMP/dev.o"
 "$LLVM/clang-offload-bundler" -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--$ARCH \
     -input=/dev/null -input="$TMP/dev.hsaco" -output="$TMP/dev.hipfb"
