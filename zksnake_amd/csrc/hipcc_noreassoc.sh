@@ -18,7 +18,7 @@ trap 'rm -rf "$TMP"' EXIT
 # (opt prints the pipeline and then fails to re-parse the writer pass it appended itself: the exit status says nothing)
 PIPE=$( ("$LLVM/opt" -O3 -print-pipeline-passes "$TMP/dev.bc" -o /dev/null 2>/dev/null || true) | sed 's/,BitcodeWriterPass//')
 case "$PIPE" in *reassociate,*) ;; *) echo "hipcc_noreassoc.sh: no reassociate pass in the O3 pipeline of this toolchain" >&2; exit 1;; esac
-PIPE=${PIPE//reassociate,/}
+[ -n "${KEEP_REASSOCIATE:-}" ] || PIPE=${PIPE//reassociate,/}   # KEEP_REASSOCIATE=1: the stock pipeline through the same stages (A/B)
 "$LLVM/opt" -mtriple=amdgcn-amd-amdhsa -mcpu=$ARCH -amdgpu-internalize-symbols -passes="$PIPE" "$TMP/dev.bc" -o "$TMP/dev.opt.bc"
 # LLCFLAGS: extra code-generation options of one translation unit (the Makefile passes a scheduling strategy for some)
 "$LLVM/llc" -mtriple=amdgcn-amd-amdhsa -mcpu=$ARCH -O3 -relocation-model=pic -filetype=obj ${LLCFLAGS:-} "$TMP/dev.opt.bc" -o "$TMP/dev.o"
