@@ -164,6 +164,11 @@ int zk_qap_h_dev(int curve, int log_n, void* d_a_u, void* d_b_v, const void* d_c
 int zk_qap_h_dev_begin(int curve, int log_n, void* d_a_u, void* d_b_v, const void* d_c, void* d_h, void* d_work, void* stream,
                        void** uv_ready);
 int zk_qap_h_dev_end(int curve, int log_n, const void* d_work, int* divisible, void* stream);
+/* Only the first third of the chain: u = iNTT(a) and / or v = iNTT(b) in place (either pointer may be NULL), enqueued on the
+ * stream, with the same "u and v are final" event.  For a rank of a task-partitioned prover whose MSM reads u or v only
+ * (python/zksnake/groth16/protocol.py:133-147: <tau_1, u>, <tau_1, v> and <tau_2, v> do not need h); no divisibility check --
+ * the rank(s) holding <target_1, h> run the whole chain and report it. */
+int zk_qap_uv_dev(int curve, int log_n, void* d_a_u, void* d_b_v, void* stream, void** uv_ready);
 
 /* ---- curve groups (ec_bn254 / ec_bls12_381 submodules) ---------------------------------- */
 
@@ -243,6 +248,11 @@ int zk_msm_plan_windows(uint64_t handle, int* window_bits, int* n_windows);
 /* the window width and count a plan over n points will use (window_bits 0 = automatic), without creating one: what a
  * rank needs to pick its share before zk_msm_plan_create_range */
 int zk_msm_window_layout(int curve, int group, uint64_t n, int flags, int window_bits, int* window_bits_out, int* n_windows);
+/* the same with the choice between the two layouts: all_windows != 0 is what zk_msm_plan_create takes (fixed-base plans of 2^20
+ * points or more: 13 windows of 20 bits), 0 what zk_msm_plan_create_range takes (16 windows of 16 bits, which split evenly).  A rank
+ * of a task-partitioned prover that holds an MSM whole uses the former. */
+int zk_msm_window_layout_ex(int curve, int group, uint64_t n, int flags, int window_bits, int all_windows, int* window_bits_out,
+                            int* n_windows);
 /* entries one window of the plan sorts and accumulates: n, or 2n when the plan runs on endomorphism pairs */
 int zk_msm_plan_entries(uint64_t handle, uint64_t* entries_per_window);
 /* milliseconds of the stages of the last zk_msm_plan_run on this plan, measured with HIP events on

@@ -1,11 +1,11 @@
-// Host build of the library's own field / curve code (csrc/field.cuh, csrc/curve.cuh are host + device): the relaxed-range
+// Host build of the library's own field / curve code (csrc/field.hip.h, csrc/curve.hip.h are host + device): the relaxed-range
 // G2 mixed addition of the accumulate kernel (xyzz_add_affine_relaxed2) against the plain formulas (xyzz_add_affine) on
 // chains of additions, both Fp2 fields, both signs, with the special cases (empty accumulator, infinity base, P + P, P - P).
 // Built and run by tests/test_host_lib.py with g++; exits non-zero on the first mismatch.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include "../../zksnake_amd/csrc/curve.cuh"
+#include "../../zksnake_amd/csrc/curve.hip.h"
 using namespace zkmi;
 
 template <class P> static Fp<P> rnd(uint64_t& s, bool small) {

@@ -266,9 +266,10 @@ def test_groth16_from_circom_with_hints(gpu):
     assert not groth16.verify(proof, forged)
 
 
-def _sharded_prove_worker(rank, world, port, curve, log_n, q, backend="gloo"):
-    """one rank of a window-sharded prove; with gloo all ranks share the box's single GPU, with nccl (= RCCL) every rank
-    owns GPU `rank` and the partial points are gathered on the device"""
+def _sharded_prove_worker(rank, world, port, curve, log_n, backend="gloo", partition="task", bad_witness=False,
+                          zk_init_after_rccl=False):
+    """one rank of a sharded prove; with gloo all ranks share the box's single GPU, with nccl (= RCCL) every rank
+    owns GPU `rank` and the partial points are gathered on the device.  Returns what the parent compares."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -291,6 +292,12 @@ def _sharded_prove_worker(rank, world, port, curve, log_n, q, backend="gloo"):
             mine = np.arange(16, dtype=np.uint64) + np.uint64(100 * rank)
             got = all_gather_limbs(mine, dev)
             assert got.shape == (world, 16) and (got[rank] == mine).all()
+            if zk_init_after_rccl:
+                # the order that broke in round 3: torch.cuda.set_device -> RCCL traffic -> the library's FIRST call.  The
+                # library must find the device torch selected (it was loaded at import then and saw "no HIP device")
+                st, qn = N._i(0), N._i(0)
+                N.check(N.load().zk_init_ex(rank, st, qn))
+                assert N.load().zk_device_count() >= 1
             E = EllipticCurve(curve)
             from zksnake_amd._algebra import _points_to_limbs
             part = _points_to_limbs([E.G1() * (rank + 5)], E.curve.curve_id, 1)[0]
@@ -299,70 +306,149 @@ def _sharded_prove_worker(rank, world, port, curve, log_n, q, backend="gloo"):
         g = Groth16(R1CS.from_triplets(A, B, C, n, n_col, 2, curve), curve)
         g._toxic, g._blinding = TOXIC, BLIND
         if rank % 2 == 0:
-            g.shard_over_ranks(dev)   # before setup(): setup prepares this rank's window range only
+            g.shard_over_ranks(dev, partition=partition)   # before setup(): setup prepares this rank's share only
             g.setup()
         else:
             g.setup()                 # after: the full-range plans prepared by setup are dropped and rebuilt by range
-            g.shard_over_ranks(dev)
+            g.shard_over_ranks(dev, partition=partition)
+        raised = None
+        if bad_witness:
+            # a witness that breaks one constraint: only the rank(s) holding <target_1, h> run the divisibility check, yet
+            # EVERY rank must leave prove() with the reference's error (the flag travels in the proof's one collective)
+            bad = list(w)
+            bad[7] = (bad[7] + 1) % cv.r
+            for _ in range(2):
+                try:
+                    g.prove(bad[:2], bad[2:])
+                    raised = "nothing"
+                except ValueError as exc:
+                    raised = str(exc)
         proof = g.prove(N.ints_to_limbs(w[:2]), N.ints_to_limbs(w[2:]))
         g._blinding = None  # drawn on rank 0 and broadcast: all ranks still agree
         proof_r = g.prove(w[:2], w[2:])
-        q.put((rank, proof.to_bytes().hex(), bool(g.verify(proof_r, w[:2])), proof_r.to_bytes().hex()))
+        mine = g._my_tasks()
+        return (proof.to_bytes().hex(), bool(g.verify(proof_r, w[:2])), proof_r.to_bytes().hex(), mine, sorted(g._qap_needs() or []), raised)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("curve,world", [("BN254", 2), ("BLS12_381", 3)])
-def test_window_sharded_prove_two_and_three_ranks(gpu, curve, world):
-    """SURVEY 8e / BASELINE config 5 shape: every rank runs its windows of the five MSMs, one all_gather of the
-    partial points, identical proof bytes on every rank = the closed form.  (RCCL needs one GPU per rank, so the
-    one-GPU box exchanges over gloo; the exchange code is the same.)"""
+def _free_port():
     import socket
-    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("curve,world,partition", [("BN254", 2, "task"), ("BLS12_381", 3, "task"), ("BN254", 5, "task"),
+                                                   ("BLS12_381", 4, "task"), ("BN254", 3, "window")])
+def test_sharded_prove_over_ranks(gpu, curve, world, partition):
+    """SURVEY 8e / BASELINE config 5 shape: the five MSMs of a proof split over the ranks by task x window (or, partition =
+    "window", every MSM by window on every rank as in rounds 1-3), one all_gather of the partial points, identical proof bytes on
+    every rank = the closed form.  (RCCL needs one GPU per rank, so the one-GPU box exchanges over gloo -- at most six processes
+    may hold the card there, this one included, hence five ranks at most; the exchange code is the same.  Eight and sixteen
+    ranks: test_simulated_ranks_... below.)"""
+    from helpers import run_ranks
     cv = pyref.curve_by_name(curve)
     log_n = 10
     n = 1 << log_n
     A, B, C, w, n_col = W.chain_circuit(n, cv.r)
     exp = _oracle_proof_bytes((list(zip(*A)), list(zip(*B)), list(zip(*C)), n, n_col, 2, w), cv).hex()
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_prove_worker, args=(r, world, port, curve, log_n, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = sorted(q.get(timeout=300) for _ in range(world))
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
-    assert [r[0] for r in results] == list(range(world))
-    assert all(r[1] == exp for r in results), "sharded proof differs from the closed form"
-    assert all(r[2] for r in results) and len({r[3] for r in results}) == 1
+    results = run_ranks(_sharded_prove_worker, world, (world, _free_port(), curve, log_n, "gloo", partition))
+    assert all(r[0] == exp for r in results), "sharded proof differs from the closed form"
+    assert all(r[1] for r in results) and len({r[2] for r in results}) == 1
+    # every window of every MSM on exactly one rank
+    covered = {}
+    for r in results:
+        for task, (first, count) in r[3].items():
+            covered.setdefault(task, []).extend(range(first, first + count))
+    assert set(covered) == {"k", "u", "v1", "v2", "h"}
+    for task, wins in covered.items():
+        assert sorted(wins) == list(range(len(wins))), (task, wins)
+    if partition == "task" and world >= 5:
+        # one MSM per rank: only the rank(s) holding <target_1, h> run the whole QAP chain
+        assert sum("h" in r[4] for r in results) < world and any(r[4] == [] for r in results)
+
+
+def test_bad_witness_fails_on_every_rank_of_a_sharded_prove(gpu):
+    """three ranks, one of which (the holder of <target_1, h>) detects the broken constraint: all three raise the reference's
+    ValueError out of the same collective instead of hanging in it, twice in a row, and then prove the good witness"""
+    from helpers import run_ranks
+    cv = pyref.BN254
+    log_n = 10
+    n = 1 << log_n
+    A, B, C, w, n_col = W.chain_circuit(n, cv.r)
+    exp = _oracle_proof_bytes((list(zip(*A)), list(zip(*B)), list(zip(*C)), n, n_col, 2, w), cv).hex()
+    results = run_ranks(_sharded_prove_worker, 3, (3, _free_port(), "BN254", log_n, "gloo", "task", True))
+    assert all(r[5] == "Failed to evaluate with the given witness" for r in results), [r[5] for r in results]
+    assert all(r[0] == exp and r[1] for r in results)
+
+
+@pytest.mark.parametrize("curve,world", [("BN254", 8), ("BLS12_381", 16)])
+def test_simulated_ranks_of_the_task_partition(gpu, curve, world, monkeypatch):
+    """the eight-rank partition of BASELINE configs[4] (and a sixteen-rank one) on ONE GPU in ONE process: every simulated rank
+    runs its share of prove() up to the collective, the rows it would have contributed are collected, and a second pass hands
+    every rank the gathered matrix.  All ranks assemble the closed-form proof; every window is covered once."""
+    from zksnake_amd import parallel
+    cv = pyref.curve_by_name(curve)
+    n = 1 << 10
+    A, B, C, w, n_col = W.chain_circuit(n, cv.r)
+    exp = _oracle_proof_bytes((list(zip(*A)), list(zip(*B)), list(zip(*C)), n, n_col, 2, w), cv).hex()
+
+    class Stop(Exception):
+        pass
+
+    rows, gathered = {}, [None]
+
+    def fake_all_gather(mine, device=None):
+        if gathered[0] is None:
+            rows[current[0]] = np.array(mine, dtype=np.uint64, copy=True)
+            raise Stop()
+        return gathered[0]
+
+    monkeypatch.setattr(parallel, "all_gather_limbs", fake_all_gather)
+    current = [0]
+    provers = []
+    for rank in range(world):
+        g = Groth16(R1CS.from_triplets(A, B, C, n, n_col, 2, curve), curve)
+        g._toxic, g._blinding = TOXIC, BLIND
+        g._shard = (rank, world, None)   # what shard_over_ranks() records, without a process group
+        g.setup()
+        provers.append(g)
+    pub, prv = N.ints_to_limbs(w[:2]), N.ints_to_limbs(w[2:])
+    for rank, g in enumerate(provers):
+        current[0] = rank
+        with pytest.raises(Stop):
+            g.prove(pub, prv)
+    gathered[0] = np.stack([rows[r] for r in range(world)])
+    for rank, g in enumerate(provers):
+        current[0] = rank
+        assert g.prove(pub, prv).to_bytes().hex() == exp, f"rank {rank}"
+    covered = {}
+    for g in provers:
+        for task, (first, count) in g._my_tasks().items():
+            covered.setdefault(task, []).extend(range(first, first + count))
+    for task in ("k", "u", "v1", "v2", "h"):
+        assert sorted(covered[task]) == list(range(len(covered[task]))), task
+    # with more ranks than MSMs most ranks hold ONE task, and few of them run the whole QAP chain
+    assert sum(len(g._my_tasks()) == 1 for g in provers) >= world - 4
+    assert sum("h" in g._qap_needs() for g in provers) <= world // 2
 
 
 def test_rccl_code_path_world_size_one(gpu):
     """the `nccl` (= RCCL) branch of the sharded path on real hardware: a one-rank group on the box's GPU runs
     all_gather_limbs / all_gather_sum on device tensors, Groth16.shard_over_ranks(device) + prove (pinned and
     broadcast blinding), so that `bench.py --gpus 8` is not the first time RCCL sees this code (RCCL wants one GPU
-    per rank: more ranks are covered over gloo above).  Child process: the process group must not leak into pytest."""
-    import socket
-    import torch.multiprocessing as mp
+    per rank: more ranks are covered over gloo above).  Child process: the process group must not leak into pytest.
+    The child also pins the load order that broke in round 3 (gpurun_out/r03d_pytest.log): torch.cuda.set_device -> RCCL ->
+    the library's first call must still find the device."""
+    from helpers import run_ranks
     curve, log_n = "BN254", 10
     cv = pyref.curve_by_name(curve)
     n = 1 << log_n
     A, B, C, w, n_col = W.chain_circuit(n, cv.r)
     exp = _oracle_proof_bytes((list(zip(*A)), list(zip(*B)), list(zip(*C)), n, n_col, 2, w), cv).hex()
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    p = ctx.Process(target=_sharded_prove_worker, args=(0, 1, port, curve, log_n, q, "nccl"))
-    p.start()
-    rank, proof_hex, verified, _ = q.get(timeout=300)
-    p.join(60)
-    assert p.exitcode == 0 and rank == 0 and proof_hex == exp and verified
+    ((proof_hex, verified, _, mine, _, _),) = run_ranks(_sharded_prove_worker, 1, (1, _free_port(), curve, log_n, "nccl", "task", False, True))
+    assert proof_hex == exp and verified and mine is None
 
 
 def test_key_file_round_trip_and_pinned_witness(gpu):

@@ -727,3 +727,50 @@ def test_point_array_plan_cache_follows_the_window_layout(gpu):
         parts.append(run(arr.plan(0, precompute=True, window_bits=12), first, count))
     assert (sum_points(cid, grp, parts) == exp).all()
     arr.release()
+
+
+@pytest.mark.parametrize("cid,grp", [(0, 1), (1, 2)])
+def test_slots_with_their_own_window_ranges_and_wide_windows(gpu, cid, grp):
+    """a rank of the task-partitioned prover may hold <tau_1, u> whole and a window range of <tau_1, v> (two slots of ONE key
+    vector with different layouts), and from 2^21 constraints on its range plans take the 20-bit windows of an unsharded plan:
+    per-slot ranges in PointArray, range plans with an explicit width, partial results that add up to the oracle's MSM"""
+    from zksnake_amd._algebra import PointArray
+    from zksnake_amd.parallel import sum_points
+    cv = pyref.BN254 if cid == 0 else pyref.BLS12_381
+    n = 1500
+    _, bases = oracle_bases(cid, grp, n, 41 + cid)
+    _, sc = rand_scalars(n, cv.r, 42 + cid)
+    exp = corc.msm(cid, grp, sc, bases, threads=8)
+    arr = PointArray(cid, grp, bases)
+
+    def run(h, first=0, count=0):
+        out = np.zeros(N.point_limbs(cid, grp), dtype=np.uint64)
+        N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, first, count, N.u64p(out), None))
+        return out
+
+    def windows(h):
+        c, nw = N._i(0), N._i(0)
+        N.check(gpu.zk_msm_plan_windows(h, c, nw))
+        return c.value, nw.value
+
+    whole = arr.plan(0, precompute=True, window_bits=20)
+    c, nw = windows(whole)
+    assert c == 20 and nw == (cv.r.bit_length() + 1 + 19) // 20 and (run(whole) == exp).all()
+    parts = []
+    cuts = [0, 4, 8, nw]
+    for first, last in zip(cuts, cuts[1:]):
+        arr.slot_ranges[1] = (first, last - first)
+        h = arr.plan(1, precompute=True, window_bits=20)
+        assert h != whole and windows(h) == (20, nw)
+        parts.append(run(h, first, last - first))
+        assert arr.plan(0, precompute=True, window_bits=20) == whole      # the other slot keeps its plan
+    assert (sum_points(cid, grp, parts) == exp).all()
+    # a range that covers everything shares the whole plan's table (a clone), and dropping the range brings it back too
+    arr.slot_ranges.pop(1)
+    h = arr.plan(1, precompute=True, window_bits=20)
+    assert h != whole and (run(h) == exp).all()
+    # concurrent=True reaches a plan that an earlier, non-concurrent caller created (round-3 advisor finding)
+    assert arr._plan_concurrent[whole] is False
+    assert arr.plan(0, precompute=True, window_bits=20, concurrent=True) == whole and arr._plan_concurrent[whole] is True
+    arr.release()
+    assert not arr._plans and not arr._plan_layout

@@ -9,8 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../zksnake_amd/csrc/msm_common.cuh"
-#include "../zksnake_amd/csrc/curve.cuh"
+#include "../zksnake_amd/csrc/msm_common.hip.h"
+#include "../zksnake_amd/csrc/curve.hip.h"
 #include "../zksnake_amd/csrc/curve_consts.h"
 using namespace zkmi;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(THREADS) void chain_kernel(const uint32_t* table, c
     }
 }
 
-// the library's accumulate kernel (msm_accumulate.cuh) with the same time stamps: sorted entry list, bucket offsets, binary
+// the library's accumulate kernel (msm_accumulate.hip.h) with the same time stamps: sorted entry list, bucket offsets, binary
 // search for the first bucket, a flush at every bucket end
 template <class FF>
 __device__ __forceinline__ uint32_t* slot_of(uint32_t* partials, uint32_t* buckets, const uint32_t* run_start, const uint32_t* bucket_start,

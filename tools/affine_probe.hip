@@ -8,7 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../zksnake_amd/csrc/curve.cuh"
+#include "../zksnake_amd/csrc/curve.hip.h"
 #include "../zksnake_amd/csrc/curve_consts.h"
 using namespace zkmi;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)

@@ -10,12 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SOURCES = {
     # the accumulate kernel and everything inlined into it
-    "msm": ("zksnake_amd/csrc/msm_impl.cuh", "zksnake_amd/csrc/msm_accumulate.cuh", "zksnake_amd/csrc/msm_common.cuh",
-            "zksnake_amd/csrc/msm_sort.cuh", "zksnake_amd/csrc/msm_reduce.cuh", "zksnake_amd/csrc/curve.cuh",
-            "zksnake_amd/csrc/field.cuh", "zksnake_amd/csrc/field_params.h", "zksnake_amd/csrc/msm_plan.h",
-            "zksnake_amd/csrc/pair.cuh", "zksnake_amd/csrc/hipcc_noreassoc.sh", "zksnake_amd/csrc/Makefile"),
+    "msm": ("zksnake_amd/csrc/msm_impl.hip.h", "zksnake_amd/csrc/msm_accumulate.hip.h", "zksnake_amd/csrc/msm_common.hip.h",
+            "zksnake_amd/csrc/msm_sort.hip.h", "zksnake_amd/csrc/msm_reduce.hip.h", "zksnake_amd/csrc/curve.hip.h",
+            "zksnake_amd/csrc/field.hip.h", "zksnake_amd/csrc/field_params.h", "zksnake_amd/csrc/msm_plan.h",
+            "zksnake_amd/csrc/pair.hip.h", "zksnake_amd/csrc/hipcc_noreassoc.sh", "zksnake_amd/csrc/Makefile"),
 }
-SOURCES["prove"] = SOURCES["msm"] + ("zksnake_amd/csrc/ntt.hip", "zksnake_amd/csrc/fr_mem.cuh", "zksnake_amd/groth16/protocol.py",
+SOURCES["prove"] = SOURCES["msm"] + ("zksnake_amd/csrc/ntt.hip", "zksnake_amd/csrc/fr_mem.hip.h", "zksnake_amd/groth16/protocol.py",
                                       "zksnake_amd/groth16/qap.py")
 
 

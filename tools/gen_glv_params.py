@@ -13,7 +13,7 @@ additions.
     c1 = round(b2 k / r),  c2 = round(-b1 k / r)        (computed as (k g_i + 2^319) >> 320, g_i = round(2^320 |b| / r))
     k1 = k - c1 a1 - c2 a2,  k2 = -c1 b1 - c2 b2        (any integers c1, c2 give a valid pair; rounding makes it short)
 
-`decompose` below is the integer formula of the kernel (glv_digits_kernel, msm_impl.cuh), word for word; the CPU tests
+`decompose` below is the integer formula of the kernel (glv_digits_kernel, msm_impl.hip.h), word for word; the CPU tests
 run it over random and extreme scalars to check the identity and the bound.  Run:  python tools/gen_glv_params.py"""
 import os
 

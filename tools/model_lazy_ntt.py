@@ -13,7 +13,7 @@ class F:
         s.p=p; s.M=limbs(p); s.INV=(-pow(p,-1,1<<29))%(1<<29)
         s.maxcol=0
     def mul(s,a,b):
-        # a, b limb lists (possibly un-normalised); product scanning as in field.cuh
+        # a, b limb lists (possibly un-normalised); product scanning as in field.hip.h
         acc=0; m=[0]*N; r=[0]*N
         for k in range(N):
             for i in range(k+1): acc+=a[i]*b[k-i]

@@ -1,4 +1,4 @@
-"""Integer model of the relaxed-range G2 mixed addition (csrc/curve.cuh, Fp2 branch of xyzz_add_affine_mem): replays the
+"""Integer model of the relaxed-range G2 mixed addition (csrc/curve.hip.h, Fp2 branch of xyzz_add_affine_mem): replays the
 limb operations on Python integers with every limb, column sum and value bound asserted, on inputs pushed to the ends of
 their ranges, and checks the results against plain modular arithmetic.  N = 9 (BN254 Fq) and N = 14 (BLS12-381 Fq)."""
 import random
@@ -28,7 +28,7 @@ class Field:
         return sum(x << (B * i) for i, x in enumerate(l))
 
     def mulk(self, pairs):
-        """(sum of a*b over the pairs) / R with one Montgomery reduction, product scanning as in field.cuh"""
+        """(sum of a*b over the pairs) / R with one Montgomery reduction, product scanning as in field.hip.h"""
         N = self.N
         acc, m, r = 0, [0] * N, [0] * N
         for k in range(2 * N - 1):

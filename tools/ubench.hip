@@ -1,4 +1,4 @@
-// tools/ubench.hip -- VALU issue-rate microbenchmark for gfx950 (design input for csrc/field.cuh).
+// tools/ubench.hip -- VALU issue-rate microbenchmark for gfx950 (design input for csrc/field.hip.h).
 // Sustained per-SIMD cost of the instructions a big-integer Montgomery product can be built from, and of the
 // library's own field operations, at 1/2/4/8 waves per SIMD.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o build/ubench tools/ubench.hip && ./build/ubench
@@ -7,7 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include "../zksnake_amd/csrc/field.cuh"
+#include "../zksnake_amd/csrc/field.hip.h"
 
 using namespace zkmi;
 

@@ -57,8 +57,11 @@ class PointArray:
         self.group = group
         self.limbs = np.ascontiguousarray(limbs, dtype=np.uint64).reshape(-1, N.point_limbs(curve_id, group))
         self._plans = {}
-        self._plan_layout = {}    # precompute flag -> (window_bits, window_range) the plans of that mode were created with
-        self.window_range = None  # (first, count): plans cover only these windows (a rank of a window-sharded prover)
+        self._plan_layout = {}    # (slot, precompute flag) -> (window_bits, window range) the plan of that key was created with
+        self._plan_concurrent = {}  # plan handle -> the "runs beside other plans" setting it carries
+        self.window_range = None  # (first, count): plans cover only these windows (a rank of a window-sharded MSM) ...
+        self.slot_ranges = {}     # ... unless the slot has a range of its own (a rank that holds different windows of <tau_1, u>
+        #                           and <tau_1, v>, Groth16.shard_over_ranks)
 
     def __len__(self):
         return self.limbs.shape[0]
@@ -115,44 +118,70 @@ class PointArray:
         window_bits 0 = the library's choice for len(self) points.  concurrent=True says that the plan runs beside other plans
         (a prover's pipelines): a NEW plan then keeps one issue priority in its accumulate kernel (plan option "priority_steps" = 0;
         the steps pay only when the kernel has the GPU to itself, include/zkmi.h)."""
-        key = (slot, bool(precompute))
-        # clones share the first plan's bases, so all plans of a mode have one window layout: a call that asks for another
-        # width, or comes after window_range changed, drops them and builds anew instead of silently handing back a plan
-        # with the old layout (round-2 advisor finding).  high_priority only picks the stream of a NEW plan.
-        layout = (int(window_bits), self.window_range)
-        have = self._plan_layout.get(bool(precompute))
-        if have is not None and (have[1] != layout[1] or (layout[0] and have[0] != layout[0])):
-            for k in [k for k in self._plans if k[1] == bool(precompute)]:
-                N.load().zk_msm_plan_destroy(self._plans.pop(k))
+        lib = N.load()
+        pre = bool(precompute)
+        key = (slot, pre)
+        # A plan is cached per (slot, mode) together with the layout it was created with.  A call that asks for another window
+        # width, or comes after the slot's window range changed, drops that plan and builds anew instead of silently handing
+        # back a plan with the old layout (round-2 advisor finding).  window_bits 0 = "whatever the mode's plans have".
+        rng = self.slot_ranges.get(slot, self.window_range)
+        have = self._plan_layout.get(key)
+        if have is not None and (have[1] != rng or (window_bits and have[0] != int(window_bits))):
+            self._drop(key)
             have = None
-        if have is None:
-            self._plan_layout[bool(precompute)] = layout
+        if window_bits == 0:
+            # another slot of the mode fixes the width (clones share one table)
+            window_bits = next((lay[0] for (s, p), lay in self._plan_layout.items() if p == pre and lay[0]), 0)
+        elif have is None:
+            # a new width for the mode: the other slots' plans were built over the old table, they go too
+            for k in [k for k, lay in self._plan_layout.items() if k[1] == pre and lay[0] != int(window_bits)]:
+                self._drop(k)
         if key not in self._plans:
             lib = N.ensure_gpu()
             h = N._u64(0)
-            other = next((v for (s, p), v in self._plans.items() if p == bool(precompute)), None)
+            other = next((self._plans[k] for k, lay in self._plan_layout.items()
+                          if k[1] == pre and lay == (int(window_bits), rng) and k in self._plans), None)
             if other is not None:
-                # further slots share the first plan's bases (and its fixed-base table): only the workspace is new
+                # further slots over the same windows share the first plan's bases (and its fixed-base table): only the
+                # workspace is new
                 N.check(lib.zk_msm_plan_clone(other, h))
             else:
                 flags = (N.MSM_PRECOMPUTE if precompute else 0) | (N.MSM_HIGH_PRIORITY if high_priority else 0)
-                if self.window_range is not None:
-                    first, count = self.window_range
+                if rng is not None:
+                    first, count = rng
                     N.check(lib.zk_msm_plan_create_range(self.curve_id, self.group, len(self), self.limbs.ctypes.data, 0, flags,
                                                          window_bits, first, count, h))
                 else:
                     N.check(lib.zk_msm_plan_create(self.curve_id, self.group, len(self), self.limbs.ctypes.data, 0, flags,
                                                    window_bits, h))
-            if concurrent:
-                N.check(lib.zk_msm_plan_set_option(h.value, b"priority_steps", 0))
             self._plans[key] = h.value
-        return self._plans[key]
+            self._plan_layout[key] = (int(window_bits), rng)
+            self._plan_concurrent[h.value] = False
+        handle = self._plans[key]
+        if concurrent and not self._plan_concurrent.get(handle):
+            # also for a plan an earlier, non-concurrent caller created (round-3 advisor finding: a direct pk.tau_1.plan() left
+            # the prover's accumulate kernels with their priority steps).  Refused while a run is in flight: tried again by the
+            # next call.
+            if lib.zk_msm_plan_set_option(handle, b"priority_steps", 0) == N.ZK_OK:
+                self._plan_concurrent[handle] = True
+        return handle
+
+    def _drop(self, key):
+        """destroy the plan of one (slot, mode); a run still in flight on it is cancelled first (waits for the plan's stream)"""
+        handle = self._plans.pop(key, None)
+        self._plan_layout.pop(key, None)
+        if handle is not None:
+            lib = N.load()
+            lib.zk_msm_plan_cancel(handle)   # status ignored: nothing in flight is the normal case
+            lib.zk_msm_plan_destroy(handle)
+            self._plan_concurrent.pop(handle, None)
 
     def release(self):
-        for h in self._plans.values():
-            N.load().zk_msm_plan_destroy(h)
+        for key in list(self._plans):
+            self._drop(key)
         self._plans = {}
         self._plan_layout = {}
+        self._plan_concurrent = {}
 
     def __del__(self):
         try:

@@ -77,6 +77,7 @@ SIGNATURES = {
     "zk_qap_h_dev": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_i), _vp]),
     "zk_qap_h_dev_begin": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
     "zk_qap_h_dev_end": (_i, [_i, _i, _vp, ctypes.POINTER(_i), _vp]),
+    "zk_qap_uv_dev": (_i, [_i, _i, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
     "zk_msm": (_i, [_i, _i, _u64, _u64, _u64p, _u64p, _u64p]),
     "zk_batch_mul": (_i, [_i, _i, _u64, _u64p, _u64p, _i, _u64p]),
     "zk_msm_plan_create": (_i, [_i, _i, _u64, _vp, _i, _i, _i, _u64p]),
@@ -93,6 +94,7 @@ SIGNATURES = {
     "zk_msm_plan_finish": (_i, [_u64, _u64p]),
     "zk_msm_plan_windows": (_i, [_u64, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "zk_msm_window_layout": (_i, [_i, _i, _u64, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "zk_msm_window_layout_ex": (_i, [_i, _i, _u64, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "zk_msm_plan_entries": (_i, [_u64, ctypes.POINTER(_u64)]),
     "zk_msm_plan_timings": (_i, [_u64, ctypes.POINTER(ctypes.c_float), _i]),
     "zk_msm_plan_set_option": (_i, [_u64, ctypes.c_char_p, ctypes.c_int64]),

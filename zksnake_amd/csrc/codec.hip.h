@@ -1,4 +1,4 @@
-// codec.cuh -- compressed point encodings, host and device (one routine per point; the batched kernels below put one
+// codec.hip.h -- compressed point encodings, host and device (one routine per point; the batched kernels below put one
 // point on a lane).
 //
 // Formats as the reference's to_bytes / from_hex produce and accept them (src/bn254/curve.rs:283-324 through
@@ -10,7 +10,7 @@
 // Key files hold millions of such points (serialization.py:60-141), hence the kernels: a square root is ~380 field
 // products and the subgroup check ~3500, all independent per point.
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 #include "curve_consts.h"
 
 namespace zkmi {

@@ -1,12 +1,12 @@
-// common.cuh -- shared plumbing of libzkmi: status/error reporting, HIP checks, curve tags.
+// common.hip.h -- shared plumbing of libzkmi: status/error reporting, HIP checks, curve tags.
 #pragma once
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include "../../include/zkmi.h"
-#include "curve.cuh"
-#include "host64.cuh"
+#include "curve.hip.h"
+#include "host64.hip.h"
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -62,7 +62,7 @@ void pinned_free_cached(void* p);
 
 struct Bn254G1 {
     typedef FpOps<BnFqParams> F;
-    typedef HostTail64<Fp64Ops<BnFqParams>> HostF;  // 64-bit-limb host arithmetic (host64.cuh)
+    typedef HostTail64<Fp64Ops<BnFqParams>> HostF;  // 64-bit-limb host arithmetic (host64.hip.h)
     typedef BnFrParams Fr;
     static constexpr int CURVE = ZK_CURVE_BN254, GROUP = ZK_G1;
     static constexpr int ENDO_ID = 2 * CURVE + GROUP;   // identity of the group's scalar split (SortExport::endo)

@@ -1,5 +1,5 @@
-// curve.cuh -- short-Weierstrass (a = 0) group arithmetic for G1 (over Fp) and G2 (over Fp2) of
-// BN254 and BLS12-381, generic over the field facade F (FpOps / Fp2Ops from field.cuh).
+// curve.hip.h -- short-Weierstrass (a = 0) group arithmetic for G1 (over Fp) and G2 (over Fp2) of
+// BN254 and BLS12-381, generic over the field facade F (FpOps / Fp2Ops from field.hip.h).
 //
 // Replaces what the reference gets from ark-ec 0.4.2 `short_weierstrass::{Affine, Projective}`
 // behind PointG1/PointG2 (src/bn254/curve.rs:19-324, src/bls12_381/curve.rs twins) and inside
@@ -9,7 +9,7 @@
 // the unique affine representative before it leaves the library, so outputs are
 // representation-independent and bit-exact against any correct implementation.
 #pragma once
-#include "field.cuh"
+#include "field.hip.h"
 
 namespace zkmi {
 

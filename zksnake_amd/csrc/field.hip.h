@@ -1,4 +1,4 @@
-// field.cuh -- prime-field arithmetic for the zksnake hot path on gfx950 (and the host side of the same
+// field.hip.h -- prime-field arithmetic for the zksnake hot path on gfx950 (and the host side of the same
 // library): 29-bit limbs, Montgomery form with R = 2^(29 N), values kept semi-reduced in [0, 2p).
 //
 // Replaces what the reference gets from ark-ff 0.4.2 `Fp<MontBackend<..>, N>` behind
@@ -628,7 +628,7 @@ ZK_HD Fp2<P> fp2_sqr(const Fp2<P>& a) {
     return {t0, fp_dbl<P>(t1)};
 }
 
-// ---- relaxed-range Fp2 pieces of the G2 bucket accumulation (curve.cuh; bounds replayed by tools/model_relaxed_g2.py) ----
+// ---- relaxed-range Fp2 pieces of the G2 bucket accumulation (curve.hip.h; bounds replayed by tools/model_relaxed_g2.py) ----
 // product with a.c1 negated lazily against K p (a.c1 < (K - 1) p): the components of a may exceed 2p as far as the value
 // bound of fp_mul2 allows, (a0 b0 + K p b1) <= R p and (a0 b1 + a1 b0) <= R p
 template <class P, int K>
@@ -691,7 +691,7 @@ struct FpOps {
     static ZK_HD T load(const uint32_t* w) { return fp_load<P>(w); }
     static ZK_HD void store(uint32_t* w, const T& a) { fp_store<P>(w, a); }
 
-    // ---- relaxed-range pieces of the bucket-accumulation step (curve.cuh, xyzz_add_affine_mem) ----
+    // ---- relaxed-range pieces of the bucket-accumulation step (curve.hip.h, xyzz_add_affine_mem) ----
     static constexpr bool RELAXED = true;
     static constexpr bool RELAXED2 = false;
     static ZK_HD T neg_for_mul(const T& a) { return fp_neg_lazy<P>(a); }                 // 4p - a, carry-free
@@ -717,7 +717,7 @@ struct Fp2Ops {
     static ZK_HD T add(const T& a, const T& b) { return fp2_add<P>(a, b); }
     static ZK_HD T sub(const T& a, const T& b) { return fp2_sub<P>(a, b); }
     static constexpr bool RELAXED = false;
-    static constexpr bool RELAXED2 = true;   // Fp2 form of the relaxed bucket-accumulation step (curve.cuh) and of pair_add (pair.cuh)
+    static constexpr bool RELAXED2 = true;   // Fp2 form of the relaxed bucket-accumulation step (curve.hip.h) and of pair_add (pair.hip.h)
     template <int K> static ZK_HD T sub_k(const T& a, const T& b) { return {fp_sub_k<P, K>(a.c0, b.c0), fp_sub_k<P, K>(a.c1, b.c1)}; }
     static ZK_HD T x3_sel4(const T& t, const T& q) { return {fp_sub_twice_sel4<P>(t.c0, q.c0), fp_sub_twice_sel4<P>(t.c1, q.c1)}; }
     template <int K> static ZK_HD T mul_rel(const T& a, const T& b) { return fp2_mul_relaxed<P, K>(a, b); }   // a.c1 < (K - 1) p

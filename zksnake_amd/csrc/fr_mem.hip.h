@@ -1,7 +1,7 @@
-// fr_mem.cuh -- load / store of one scalar-field element between HBM (W packed 32-bit words, 16-byte vector
+// fr_mem.hip.h -- load / store of one scalar-field element between HBM (W packed 32-bit words, 16-byte vector
 // accesses) and registers (N 29-bit limbs).  Shared by ntt.hip and plonk.hip.
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace zkmi {
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Compiles one HIP translation unit like `hipcc -c`, with ONE change in the device pipeline: LLVM's O3 pass pipeline runs without
-# its `reassociate` pass.  Why: the field products are written as one accumulator chain per column (field.cuh); `reassociate`,
+# its `reassociate` pass.  Why: the field products are written as one accumulator chain per column (field.hip.h); `reassociate`,
 # run on the straight-line code that is left after the __forceinline__ layers have been inlined, sorts every column sum by operand
 # rank -- products first, the carry of the previous column last -- which starts each column from zero and spends one 64-bit add
 # per column on joining the carry: 146 of the 2298 VALU instructions of a BN254 G1 bucket addition.  The

@@ -13,15 +13,15 @@
 #include <map>
 #include <mutex>
 #include <vector>
-#include "common.cuh"
-#include "codec.cuh"
+#include "common.hip.h"
+#include "codec.hip.h"
 
 extern "C" void zk_ntt_free_cache(void);
 extern "C" void zk_msm_free_all(void);
 
 namespace zkmi {
 
-// ---- caching device allocator (common.cuh) ----------------------------------------------------------------
+// ---- caching device allocator (common.hip.h) ----------------------------------------------------------------
 static std::mutex g_cache_mutex;
 static std::multimap<size_t, void*> g_cache_free;          // size -> block
 static std::map<void*, size_t> g_cache_live;               // block -> size, for blocks handed out through the cache
@@ -162,7 +162,7 @@ static void store_point(uint64_t* dst, const Affine<typename G::F>& p) {
     F::to_canonical(w + F::LIMBS, p.y);
 }
 
-// the same on the 64-bit-limb host arithmetic (host64.cuh): add / sum / scalar multiplication of single points, what a
+// the same on the 64-bit-limb host arithmetic (host64.hip.h): add / sum / scalar multiplication of single points, what a
 // proof's assembly spends its host time on (~20 operations per proof, python/zksnake/groth16/protocol.py:133-163)
 template <class G>
 static Affine<typename G::HostF> load_point64(const uint64_t* src) {
@@ -192,7 +192,7 @@ static void reduce_scalar(uint32_t* k, const uint64_t* scalar) {
     }
 }
 
-// ---- compressed encodings (codec.cuh holds the arithmetic, shared with the batched GPU kernels) ----------
+// ---- compressed encodings (codec.hip.h holds the arithmetic, shared with the batched GPU kernels) ----------
 
 template <class G>
 static int compress_impl(const uint64_t* a, uint8_t* out) {

@@ -1,7 +1,7 @@
-// host64.cuh -- prime-field arithmetic on 64-bit limbs for the HOST side of the library: the sequential tail of an MSM
+// host64.hip.h -- prime-field arithmetic on 64-bit limbs for the HOST side of the library: the sequential tail of an MSM
 // (Horner over the windows: c doublings per window, one inversion) and single-point operations.
 //
-// The device representation (29-bit limbs, field.cuh) is built around what a GPU lane can issue; on an x86 core the same
+// The device representation (29-bit limbs, field.hip.h) is built around what a GPU lane can issue; on an x86 core the same
 // product is a 4 x 4 (BN254) or 6 x 6 (BLS12-381) schoolbook on 64 x 64 -> 128-bit multiplications, about three times
 // faster than running the 29-bit code there.  What the reference does at this point is ark-ff's 64-bit Montgomery
 // arithmetic as well (ark-ff 0.4.2 `MontBackend`, behind src/bn254/curve.rs:77-132 point operations).
@@ -11,7 +11,7 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
-#include "curve.cuh"
+#include "curve.hip.h"
 
 namespace zkmi {
 

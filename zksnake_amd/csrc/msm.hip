@@ -1,8 +1,8 @@
 // msm.hip -- C API of the MSM / batch multiplication entry points (include/zkmi.h); the kernels live in
-// msm_impl.cuh and are instantiated per curve group in msm_group.hip.
+// msm_impl.hip.h and are instantiated per curve group in msm_group.hip.
 #include <map>
 #include <mutex>
-#include "common.cuh"
+#include "common.hip.h"
 #include "msm_plan.h"
 
 namespace zkmi {
@@ -148,11 +148,17 @@ int zk_msm_plan_finish(uint64_t handle, uint64_t* out) {
 }
 
 int zk_msm_window_layout(int curve, int group, uint64_t n, int flags, int window_bits, int* window_bits_out, int* n_windows) {
-    // the same rule as MsmPlan::init (msm_plan.h: msm_layout), for a rank's share of a window-sharded MSM
+    return zk_msm_window_layout_ex(curve, group, n, flags, window_bits, 0, window_bits_out, n_windows);
+}
+
+int zk_msm_window_layout_ex(int curve, int group, uint64_t n, int flags, int window_bits, int all_windows, int* window_bits_out,
+                            int* n_windows) {
+    // the same rule as MsmPlan::init (msm_plan.h: msm_layout): for a rank's share of a window-sharded MSM (all_windows = 0) or
+    // for a plan over every window (zk_msm_plan_create)
     if (curve != ZK_CURVE_BN254 && curve != ZK_CURVE_BLS12_381) return fail(ZK_ERR_ARG, "unknown curve");
     if (group != ZK_G1 && group != ZK_G2) return fail(ZK_ERR_ARG, "unknown group");
     const int bits = curve == ZK_CURVE_BN254 ? BnFrParams::BITS : BlsFrParams::BITS;
-    const MsmLayout lay = msm_layout(bits, true /* all four groups split their scalars */, n, flags, window_bits, false);
+    const MsmLayout lay = msm_layout(bits, true /* all four groups split their scalars */, n, flags, window_bits, all_windows != 0);
     if (lay.c < 2 || lay.c > 20) return fail(ZK_ERR_ARG, "window bits must be in [2, 20]");
     *window_bits_out = lay.c;
     *n_windows = lay.nwin;

@@ -1,7 +1,7 @@
-// msm_accumulate.cuh -- stage 5 of the MSM pipeline, the dominant kernel (bucket accumulation over uniform segments of the
-// sorted entry list), and the conversion of the bases to Montgomery form.  Pipeline overview: msm_impl.cuh.
+// msm_accumulate.hip.h -- stage 5 of the MSM pipeline, the dominant kernel (bucket accumulation over uniform segments of the
+// sorted entry list), and the conversion of the bases to Montgomery form.  Pipeline overview: msm_impl.hip.h.
 #pragma once
-#include "msm_common.cuh"
+#include "msm_common.hip.h"
 
 namespace zkmi {
 

@@ -1,9 +1,9 @@
-// msm_common.cuh -- device load / store of points, register-form copies and the endomorphism traits shared by the MSM
-// kernel headers (msm_sort.cuh, msm_accumulate.cuh, msm_reduce.cuh) and the plan (msm_impl.cuh).
+// msm_common.hip.h -- device load / store of points, register-form copies and the endomorphism traits shared by the MSM
+// kernel headers (msm_sort.hip.h, msm_accumulate.hip.h, msm_reduce.hip.h) and the plan (msm_impl.hip.h).
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 #include "msm_plan.h"
-#include "pair.cuh"
+#include "pair.hip.h"
 #include "glv_params.h"
 
 namespace zkmi {

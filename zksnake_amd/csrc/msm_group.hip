@@ -6,7 +6,7 @@
 //   ZK_PART 2: combine (3 tiers) / strided_sum / weighted_sum kernels
 //   ZK_PART 3: setup-side kernels (batched normalisation, fixed-base table rows, batch scalar multiplication,
 //              batched point (de)compression)
-#include "msm_impl.cuh"
+#include "msm_impl.hip.h"
 
 #ifndef ZK_GROUP
 #error "compile with -DZK_GROUP=<Bn254G1|Bn254G2|Bls381G1|Bls381G2> -DZK_PART=<0|1|2>"

@@ -1,4 +1,4 @@
-// msm_impl.cuh -- Pippenger bucket multi-scalar multiplication over G1/G2 of BN254 and BLS12-381 on
+// msm_impl.hip.h -- Pippenger bucket multi-scalar multiplication over G1/G2 of BN254 and BLS12-381 on
 // gfx950, plus batched scalar multiplication.
 //
 // Stands in for multiscalar_mul_g1/_g2 (reference src/bn254/curve.rs:356-392,
@@ -28,19 +28,19 @@
 #include <chrono>
 #include <memory>
 #include <vector>
-#include "common.cuh"
+#include "common.hip.h"
 #include "msm_plan.h"
-#include "pair.cuh"
-#include "setup_impl.cuh"
-#include "codec.cuh"
+#include "pair.hip.h"
+#include "setup_impl.hip.h"
+#include "codec.hip.h"
 #include "glv_params.h"
 
-#include "msm_common.cuh"
+#include "msm_common.hip.h"
 #if !defined(ZK_PART) || ZK_PART == 0  // sort-stage kernels and the plan live in part 0 only
-#include "msm_sort.cuh"
+#include "msm_sort.hip.h"
 #endif
-#include "msm_accumulate.cuh"
-#include "msm_reduce.cuh"
+#include "msm_accumulate.hip.h"
+#include "msm_reduce.hip.h"
 
 namespace zkmi {
 
@@ -577,7 +577,7 @@ struct MsmPlan : MsmPlanBase {
         if (gate) ZK_HIP(hipStreamWaitEvent(st, gate, 0));
         l.acc_from_accs = gate != nullptr || phase == 2;
         if (l.acc_from_accs) ZK_HIP(hipEventRecord(l.ev_accs, st));
-        // priority steps (msm_accumulate.cuh) for a run in one piece that waits for nothing: the two-step, gated and shared forms
+        // priority steps (msm_accumulate.hip.h) for a run in one piece that waits for nothing: the two-step, gated and shared forms
         // are what a prover uses to overlap several plans
         const bool prio_steps = opt.priority_steps && phase == 0 && !gate && !borrowed;
         if ((rc = stage_accumulate(m, seg_len, st, p_sorted, p_bstart, p_sstart, p_big_list, p_big_count, prio_steps))) return rc;
@@ -758,7 +758,7 @@ struct MsmPlan : MsmPlanBase {
         if (q_sorted) return fail(ZK_ERR_ARG, "zk_msm_plan_finish before zk_msm_plan_enqueue_rest");
         if (!q_pending) return fail(ZK_ERR_ARG, "zk_msm_plan_finish without a pending run");
         q_pending = false;
-        typedef typename G::HostF HF;  // 64-bit-limb host arithmetic for the sequential tail (host64.cuh)
+        typedef typename G::HostF HF;  // 64-bit-limb host arithmetic for the sequential tail (host64.hip.h)
         XYZZ<HF> total = xyzz_inf<HF>();
         std::chrono::steady_clock::time_point tail_t0;
         if (q_m > 0) {

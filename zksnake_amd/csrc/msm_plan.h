@@ -11,7 +11,7 @@
 namespace zkmi {
 
 // a device allocation with shared ownership (the bases / fixed-base table of a plan and its clones)
-void dev_free_cached(void* p);  // common.cuh / host.hip
+void dev_free_cached(void* p);  // common.hip.h / host.hip
 struct DeviceBlock {
     void* ptr = nullptr;
     ~DeviceBlock() { dev_free_cached(ptr); }
@@ -112,7 +112,7 @@ struct MsmOptions {
     uint32_t lanes_per_output = 0;           // ZKMI_LPO: lanes per row / column sum of the one-step form (0 = by output count)
     bool two_level_sort = true;              // ZKMI_NO_TWO_LEVEL clears it: one-level / bucket-range sorts only (c <= 16)
     bool priority_steps = true;              // ZKMI_NO_PRIO_STEPS clears it: accumulate waves step their issue priority down near the
-                                             // end of their segment (plain runs only, msm_accumulate.cuh)
+                                             // end of their segment (plain runs only, msm_accumulate.hip.h)
     // layout (creation time only)
     uint32_t sort_workgroups = 256;          // ZKMI_SORT_WGS: bucket-range sort workgroups over all windows
     int fine_log = 0;                        // ZKMI_FINE_LOG: fine bucket bits of the two-level sort (0 = automatic)

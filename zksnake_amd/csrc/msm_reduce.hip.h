@@ -1,13 +1,13 @@
-// msm_reduce.cuh -- stages 6-7 of the MSM pipeline: per-bucket combination of the segment partials and the bucket
-// reduction sum_b (b + 1) B_b on lane pairs (pair.cuh).  Pipeline overview: msm_impl.cuh.
+// msm_reduce.hip.h -- stages 6-7 of the MSM pipeline: per-bucket combination of the segment partials and the bucket
+// reduction sum_b (b + 1) B_b on lane pairs (pair.hip.h).  Pipeline overview: msm_impl.hip.h.
 #pragma once
-#include "msm_common.cuh"
+#include "msm_common.hip.h"
 
 namespace zkmi {
 
 // ---- 6. combine ---------------------------------------------------------------------------------
 // bucket = sum of its runs, three tiers in ONE launch (every dependent launch costs ~5 us of latency, and the two upper
-// tiers are empty unless the scalars are skewed).  A point is held by a lane pair (pair.cuh) in all tiers.
+// tiers are empty unless the scalars are skewed).  A point is held by a lane pair (pair.hip.h) in all tiers.
 //   blocks [0, small_blocks)                 one pair per bucket with 2 .. COMBINE_SMALL_MAX runs
 //   blocks [small_blocks, + COMBINE_WAVE_BLOCKS)  one wave (32 pairs) per listed bucket, <= COMBINE_WAVE_MAX runs
 //   the rest                                 one workgroup (128 pairs) per listed bucket
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(COMBINE_THREADS) void combine_kernel(const uint32_t
 }
 
 // ---- 7. bucket reduction ----------------------------------------------------------------------------
-// Both kernels hold a point as a lane pair (pair.cuh): an addition is seven multiplications deep instead of
+// Both kernels hold a point as a lane pair (pair.hip.h): an addition is seven multiplications deep instead of
 // fourteen and a half, which is what these latency-bound stages are made of.
 
 // Two strided sums in one launch (rows and columns run side by side):

@@ -1,8 +1,8 @@
-// msm_sort.cuh -- stages 1-4 of the MSM pipeline: scalar digits (plain and split by the endomorphism), the one-level,
+// msm_sort.hip.h -- stages 1-4 of the MSM pipeline: scalar digits (plain and split by the endomorphism), the one-level,
 // bucket-range and two-level counting sorts, and the scans between them.  Group-independent: compiled into part 0 of every
-// group translation unit only (msm_group.hip).  Pipeline overview: msm_impl.cuh.
+// group translation unit only (msm_group.hip).  Pipeline overview: msm_impl.hip.h.
 #pragma once
-#include "msm_common.cuh"
+#include "msm_common.hip.h"
 
 namespace zkmi {
 

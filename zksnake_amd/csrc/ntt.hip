@@ -17,8 +17,8 @@
 #include <mutex>
 #include <map>
 #include <vector>
-#include "common.cuh"
-#include "fr_mem.cuh"
+#include "common.hip.h"
+#include "fr_mem.hip.h"
 
 namespace zkmi {
 
@@ -952,6 +952,20 @@ int zk_qap_h_dev_begin(int curve, int log_n, void* d_a_u, void* d_b_v, const voi
 #define CALL(P) return qap_h_dev_impl<P>(curve, log_n, (uint32_t*)d_a_u, (uint32_t*)d_b_v, (const uint32_t*)d_c, (uint32_t*)d_h, (uint32_t*)d_work, nullptr, (hipStream_t)stream, ev)
     ZK_DISPATCH_FR(curve, CALL);
 #undef CALL
+}
+
+int zk_qap_uv_dev(int curve, int log_n, void* d_a_u, void* d_b_v, void* stream, void** uv_ready) {
+    hipEvent_t ev = nullptr;
+    if (uv_ready) {
+        int rc = uv_event_for((hipStream_t)stream, &ev);
+        if (rc) return rc;
+        *uv_ready = (void*)ev;
+    }
+    int rc = ZK_OK;
+    if (d_a_u && (rc = zk_ntt_dev(curve, 1, log_n, d_a_u, stream))) return rc;
+    if (d_b_v && (rc = zk_ntt_dev(curve, 1, log_n, d_b_v, stream))) return rc;
+    if (ev) ZK_HIP(hipEventRecord(ev, (hipStream_t)stream));
+    return ZK_OK;
 }
 
 int zk_qap_h_dev_end(int curve, int log_n, const void* d_work, int* divisible, void* stream) {

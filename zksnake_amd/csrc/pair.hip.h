@@ -1,6 +1,6 @@
-// pair.cuh -- one XYZZ point held by a LANE PAIR: the even lane keeps (X, ZZ), the odd lane (Y, ZZZ).
+// pair.hip.h -- one XYZZ point held by a LANE PAIR: the even lane keeps (X, ZZ), the odd lane (Y, ZZZ).
 //
-// The bucket-reduction stages of the MSM (msm_impl.cuh stages 6-7) are latency-bound: few points, long chains of
+// The bucket-reduction stages of the MSM (msm_impl.hip.h stages 6-7) are latency-bound: few points, long chains of
 // dependent additions, most SIMDs idle.  A single lane needs the 12M + 2S of add-2008-s one after the other (~9 us per
 // addition for BN254 G1 at lone-wave speed).  Split over two lanes the same addition is SEVEN multiplications deep,
 // both lanes run the same instruction stream (only the operands differ), and no lane is wasted:
@@ -20,7 +20,7 @@
 // reference (ark's MSM reduces its buckets with a serial running sum on one core, src/bn254/curve.rs:356-373 ->
 // ark-ec VariableBaseMSM); this is how the same sum is laid out for 64-wide waves.
 #pragma once
-#include "curve.cuh"
+#include "curve.hip.h"
 
 namespace zkmi {
 
@@ -134,7 +134,7 @@ __device__ __forceinline__ HalfPt<F> pair_add(const HalfPt<F>& p, const HalfPt<F
     if (half_is_inf<F>(p)) return q;
     if constexpr (F::RELAXED) {
         // Base-field groups: the differences that only feed products skip the range selection (carries only), as in the
-        // accumulate step (curve.cuh): 480 -> 268 instructions outside the seven products of the chain.  X may sit in [0, 4p)
+        // accumulate step (curve.hip.h): 480 -> 268 instructions outside the seven products of the chain.  X may sit in [0, 4p)
         // (it only ever meets products); Y, ZZ, ZZZ stay below 2p (Y is doubled with a range-selecting addition in xyzz_dbl).
         //   d = m2 - m1 + 2p < 4p;  dd = d^2 (16 <= R/p);  PPP = d dd (8);  X3 = RR - PPP + 2p - 2Q in [0, 4p);
         //   Q - X3 + 4p < 6p;  R (Q - X3) (4 * 6 = 24)

@@ -4,14 +4,14 @@
 // `Bn254::multi_pairing`, bls12_381 twin), which also run on the CPU; only Groth16.verify uses them
 // (python/zksnake/groth16/protocol.py:167-186).  SURVEY.md 8f row 3.
 //
-// Tower: Fp2 = Fp[u]/(u^2+1) (field.cuh), Fp12 = Fp2[w]/(w^6 - xi), xi = 9+u (BN254) / 1+u (BLS12-381);
+// Tower: Fp2 = Fp[u]/(u^2+1) (field.hip.h), Fp12 = Fp2[w]/(w^6 - xi), xi = 9+u (BN254) / 1+u (BLS12-381);
 // an Fp12 element is six Fp2 coefficients of 1, w, .., w^5.  The Miller loop keeps T affine on the twist
 // (one Fp2 inversion per step); the final exponentiation is f -> conj(f)/f, then a plain square-and-multiply by (p^6+1)/r --
-// ~10 ms on 64-bit limbs (host64.cuh), which keeps the code free of curve-specific Frobenius tables (only the two BN254
+// ~10 ms on 64-bit limbs (host64.hip.h), which keeps the code free of curve-specific Frobenius tables (only the two BN254
 // loop-tail points need the twist Frobenius constants).  Groth16.verify folds its four pairings into ONE call, i.e. one
 // final exponentiation.
 #include <vector>
-#include "common.cuh"
+#include "common.hip.h"
 #include "pairing_params.h"
 
 namespace zkmi {
@@ -23,7 +23,7 @@ struct Fp12 {
 
 template <class P, class PP>
 struct PairingEngine {
-    // host arithmetic on 64-bit limbs (host64.cuh): this engine never runs on the device
+    // host arithmetic on 64-bit limbs (host64.hip.h): this engine never runs on the device
     typedef Fp64Ops<P> B;
     typedef Fp2Ops64<P> O2;
     typedef Fp64<P> E1;

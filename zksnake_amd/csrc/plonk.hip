@@ -13,8 +13,8 @@
 // Roofline: the quotient kernel reads 15 vectors and writes one (512 B per point) against 22 field products;
 // at ~1000 cycles per product per wave it is integer-multiply bound like everything else on this path.
 #include <vector>
-#include "common.cuh"
-#include "fr_mem.cuh"
+#include "common.hip.h"
+#include "fr_mem.hip.h"
 
 namespace zkmi {
 

@@ -1,4 +1,4 @@
-// setup_impl.cuh -- setup-side group kernels: batched normalisation (XYZZ -> affine with ONE field inversion per
+// setup_impl.hip.h -- setup-side group kernels: batched normalisation (XYZZ -> affine with ONE field inversion per
 // 1024 points), the fixed-base table 2^(c w) P_i of ZK_MSM_PRECOMPUTE plans, and fixed-base batch scalar
 // multiplication.
 //
@@ -9,7 +9,7 @@
 #pragma once
 #include <map>
 #include <vector>
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace zkmi {
 

@@ -10,9 +10,13 @@ and the five MSM results on the GPU:
 The proving key vectors are `PointArray`s whose Montgomery-form bases stay resident in HBM
 (MSM plans), so a prove moves one witness up and three points down.
 
-Multi-GPU (BASELINE config 5): after `shard_over_ranks()` every rank evaluates the QAP
-(replicated, ~1.5 ms at 2^20) and runs only ITS windows of the five MSMs; the five partial points of all
-ranks travel in one all_gather (RCCL) and every rank assembles the same proof.
+Multi-GPU (BASELINE config 5): after `shard_over_ranks()` the five MSMs -- the reference's five independent
+`multiexp` calls, protocol.py:133-155 -- are laid on one line of (task, window) units that is cut into one contiguous piece
+per rank (zksnake_amd/parallel.py: partition_proof): a rank runs one MSM, or a window range of the G2 one, and evaluates only
+the part of the QAP its scalars need (nothing for <kdelta_1, w>, one sparse product + one inverse transform for u or v, the
+whole chain only for h).  The partial points of all ranks and an ok flag travel in ONE all_gather (RCCL) and every rank
+assembles the same proof.  `partition="window"` keeps the layout of rounds 1-3 (every rank a window range of every MSM and
+the whole QAP) for comparison.
 """
 
 import os
@@ -40,6 +44,11 @@ def _as_array(E, pts, group):
     return PointArray(cid, group, _points_to_limbs(pts, cid, group))
 
 
+def _ptr(buf):
+    """device address of a QAP output, None when this rank did not compute it (its MSM then has no window here either)"""
+    return buf.ptr if buf is not None else None
+
+
 class Groth16:
     def __init__(self, r1cs: R1CS, curve: str = "BN254"):
         self.E = EllipticCurve(curve)
@@ -55,6 +64,12 @@ class Groth16:
         self._collective_ms = 0.0
         self._live = []         # MSM plan handles with a run in flight (prove() cancels them when it fails half way)
         self._shard = None      # (rank, world, torch device or None) once shard_over_ranks() was called
+        self._partition = "task"
+        self._assignment = None  # per rank {task: (first window, count)}, computed when the key sizes are known
+        self._n_windows = {}     # task -> window count of its MSM in the sharded layout
+        self._task_bits = {}     # task -> explicit window width of its plans (empty: the library's choice)
+        self.projected_ms = None  # the partition's cost model, per rank (parallel.partition_proof)
+        self._exchanged = True   # False between the first enqueue and the collective of a sharded prove()
 
     # ------------------------------------------------------------------------------------------
     def setup(self, prepare_prover=True):
@@ -95,8 +110,7 @@ class Groth16:
         tau_G1 = self.E.batch_mul(G1, powers, as_array=True)
         tau_G2 = self.E.batch_mul(G2, powers, as_array=True)
         target_G1 = self.E.batch_mul(G1, shifted, as_array=True)
-        worker = self._start_plan_worker([(tau_G1, 1, 0, False), (tau_G2, 2, 0, True), (tau_G1, 1, 1, False), (target_G1, 1, 0, False)]) \
-            if prepare_prover else None
+        worker = self._start_plan_worker([(tau_G1, "u"), (tau_G2, "v2"), (tau_G1, "v1"), (target_G1, "h")]) if prepare_prover else None
 
         sums = []
         for mat in (self.qap.a, self.qap.b, self.qap.c):
@@ -122,8 +136,8 @@ class Groth16:
             if worker.error is not None:
                 raise worker.error
             if n_wires > n_pub:
-                self._build_plan(k_delta_G1, 1, 0, False)
-            self.qap._device_matrices()
+                self._build_plan(k_delta_G1, "k")
+            self.qap._device_matrices(self._qap_needs())
             self.qap._workspace(n, n_wires)
             self.qap._qap_stream()
 
@@ -133,23 +147,73 @@ class Groth16:
         self.verifying_key = VerifyingKey(alpha_G1, beta_G2, gamma_G2, delta_G2, k_gamma_G1)
 
     # ------------------------------------------------------------------------------------------
-    def _plan_range(self, arr):
-        """(first, count) of this rank's windows for an MSM over `arr`, or None without sharding"""
+    # task -> (slot of its PointArray, stream priority): <tau_1, u> and <tau_1, v> are two slots over one key vector
+    _TASK_SLOT = {"k": (0, False), "u": (0, False), "v1": (1, False), "v2": (0, True), "h": (0, False)}
+
+    def _task_sizes(self):
+        """points per MSM of prove(): from the key when there is one, else from the QAP's shape (what setup() will build)"""
+        pk = self.proving_key
+        n, n_wires, n_pub = self.qap.a.n_row, self.qap.a.n_col, self.qap.n_public
+        if pk is not None:
+            return {"k": len(pk.kdelta_1), "u": min(n, len(pk.tau_1)), "v1": min(n, len(pk.tau_1)), "v2": min(n, len(pk.tau_2)),
+                    "h": min(n, len(pk.target_1))}
+        return {"k": n_wires - n_pub, "u": n, "v1": n, "v2": n, "h": n}
+
+    def _my_tasks(self):
+        """{task: (first window, count)} of this rank, or None without sharding.  Every rank computes the same table."""
         if self._shard is None or self._shard[1] <= 1:
             return None
-        from ..parallel import window_ranges
-        c, nwin = N.ctypes.c_int(0), N.ctypes.c_int(0)
-        flags = N.MSM_PRECOMPUTE if self.precompute_keys else 0
-        N.check(N.load().zk_msm_window_layout(self.E.curve.curve_id, arr.group, len(arr), flags, 0, c, nwin))
-        return window_ranges(nwin.value, self._shard[1])[self._shard[0]]
+        if self._assignment is None:
+            from ..parallel import TASK_GROUP, partition_proof, window_partition
+            lib, cid = N.load(), self.E.curve.curve_id
+            flags = N.MSM_PRECOMPUTE if self.precompute_keys else 0
+            sizes = self._task_sizes()
+            n_windows, whole, bits = {}, {}, {}
+            # From 2^21 constraints on every plan of the task partition, split or whole, takes the layout of an unsharded plan
+            # (13 windows of 20 bits: 19 % fewer bucket additions than 16 of 16; the larger shared bucket set costs 0.2-0.6 ms per
+            # rank, less than the additions saved).  At 2^20 and below only ranks that hold an MSM whole do (_task_range).
+            wide = self._partition == "task" and self.qap.a.n_row >= (1 << 21)
+            for task, count in sizes.items():
+                if count > 0:
+                    c, nwin = N.ctypes.c_int(0), N.ctypes.c_int(0)
+                    N.check(lib.zk_msm_window_layout_ex(cid, TASK_GROUP[task], count, flags, 0, 1, c, nwin))
+                    whole[task] = nwin.value
+                    if wide:
+                        n_windows[task], bits[task] = nwin.value, c.value
+                    else:
+                        N.check(lib.zk_msm_window_layout_ex(cid, TASK_GROUP[task], count, flags, 0, 0, c, nwin))
+                        n_windows[task] = nwin.value
+            self._n_windows, self._task_bits = n_windows, bits
+            if self._partition == "window":
+                self._assignment = window_partition(self._shard[1], n_windows)
+                self.projected_ms = None
+            else:
+                self._assignment, self.projected_ms = partition_proof(self._shard[1], n_windows, cid, self.qap.a.n_row, whole, wide)
+        return self._assignment[self._shard[0]]
 
-    def _build_plan(self, arr, group, slot, high_priority):
-        rng = self._plan_range(arr)
+    def _task_range(self, task):
+        """this rank's (first, count) windows of `task` (count 0: none); None = the whole MSM in the layout of an unsharded plan
+        (no sharding, or a rank of the task partition that holds this MSM whole: 13 wide windows instead of 16 from 2^20 points
+        on)"""
+        mine = self._my_tasks()
+        if mine is None:
+            return None
+        rng = mine.get(task, (0, 0))
+        if self._partition == "task" and rng[1] and rng[1] == self._n_windows.get(task):
+            return None
+        return rng
+
+    def _build_plan(self, arr, task):
+        slot, high_priority = self._TASK_SLOT[task]
+        rng = self._task_range(task)
         if rng is not None:
             if rng[1] == 0:
                 return None
-            arr.window_range = rng
-        return arr.plan(slot, precompute=self.precompute_keys, high_priority=high_priority, concurrent=True)
+            arr.slot_ranges[slot] = rng
+        else:
+            arr.slot_ranges.pop(slot, None)
+        return arr.plan(slot, precompute=self.precompute_keys, high_priority=high_priority, concurrent=True,
+                        window_bits=self._task_bits.get(task, 0))
 
     def prepare_prover(self):
         """build what the first prove() would otherwise build: the fixed-base MSM plans of the proving key and the QAP's
@@ -160,14 +224,21 @@ class Groth16:
         pk = self.proving_key
         pk.tau_1, pk.tau_2 = _as_array(self.E, pk.tau_1, 1), _as_array(self.E, pk.tau_2, 2)
         pk.target_1, pk.kdelta_1 = _as_array(self.E, pk.target_1, 1), _as_array(self.E, pk.kdelta_1, 1)
-        for arr, group, slot, hp in ((pk.tau_1, 1, 0, False), (pk.tau_2, 2, 0, True), (pk.tau_1, 1, 1, False), (pk.target_1, 1, 0, False),
-                                     (pk.kdelta_1, 1, 0, False)):
+        for arr, task in ((pk.tau_1, "u"), (pk.tau_2, "v2"), (pk.tau_1, "v1"), (pk.target_1, "h"), (pk.kdelta_1, "k")):
             if len(arr):
-                self._build_plan(arr, group, slot, hp)
+                self._build_plan(arr, task)
         n, n_wires = self.qap.a.n_row, self.qap.a.n_col
-        self.qap._device_matrices()
+        self.qap._device_matrices(self._qap_needs())
         self.qap._workspace(n, n_wires)
         self.qap._qap_stream()
+
+    def _qap_needs(self):
+        """which of the QAP's outputs this rank's MSMs read: a subset of {"u", "v", "h"}; None = everything (no sharding)"""
+        mine = self._my_tasks()
+        if mine is None:
+            return None
+        from ..parallel import TASK_NEEDS
+        return {TASK_NEEDS[t] for t in mine} - {"w"}
 
     def _start_plan_worker(self, jobs):
         import threading
@@ -175,8 +246,8 @@ class Groth16:
         def run():
             try:
                 N.bind_thread()
-                for arr, group, slot, hp in jobs:
-                    self._build_plan(arr, group, slot, hp)
+                for arr, task in jobs:
+                    self._build_plan(arr, task)
             except Exception as exc:  # noqa: BLE001 - re-raised by the caller after join()
                 worker.error = exc
 
@@ -185,41 +256,52 @@ class Groth16:
         worker.start()
         return worker
 
-    def shard_over_ranks(self, device=None):
-        """split the windows of every MSM in prove() over the ranks of the default torch.distributed group
-        (one process per GPU; backend nccl = RCCL, or gloo).  `device` is where the gathered partial points
-        are staged (the rank's GPU for RCCL, None for gloo).  Call it BEFORE setup() so that the plans built there cover
-        this rank's windows only; plans that already exist for all windows are dropped and rebuilt by range on the next
-        prove()."""
+    def shard_over_ranks(self, device=None, partition="task"):
+        """split prove() over the ranks of the default torch.distributed group (one process per GPU; backend nccl = RCCL, or
+        gloo).  partition="task" (default): the task x window partition of parallel.partition_proof -- a rank runs one MSM (or a
+        window range of a long one) and only the part of the QAP that MSM needs; "window": every rank runs a window range of every
+        MSM and the whole QAP (rounds 1-3).  `device` is where the gathered partial points are staged (the rank's GPU for RCCL,
+        None for gloo).  Call it BEFORE setup() so that the plans built there cover this rank's share only; plans that already
+        exist for other windows are dropped and rebuilt on the next prove()."""
         import torch.distributed as dist
+        if partition not in ("task", "window"):
+            raise ValueError("partition must be 'task' or 'window'")
         self._shard = (dist.get_rank(), dist.get_world_size(), device)
+        self._partition = partition
+        self._assignment = None
         if self._shard[1] > 1 and self.proving_key is not None:
             pk = self.proving_key
             for arr in (pk.tau_1, pk.tau_2, pk.target_1, pk.kdelta_1):
-                if isinstance(arr, PointArray) and arr.window_range is None:
-                    arr.release()
+                if isinstance(arr, PointArray):
+                    arr.release()   # rebuilt for this rank's windows by the next prove() / prepare_prover()
+                    arr.slot_ranges = {}
 
-    def _enqueue_msm(self, bases, group, d_scalars, count, slot=0, high_priority=False, share_sort_of=None, sort_only=False,
-                     wait_event=None):
+    def _enqueue_msm(self, bases, task, d_scalars, count, share_sort_of=None, sort_only=False, wait_event=None):
         """start <bases[:count], scalars> (scalars already in HBM) on the plan's own stream; with sharding only
-        this rank's windows.  Returns (array, handle); handle None = this rank has no window of that MSM.
+        this rank's windows of `task`.  Returns (array, handle); handle None = this rank has no window of that MSM.
         sort_only: digits and sort only -- the accumulate kernel and the reduction follow with _enqueue_rest."""
+        from ..parallel import TASK_GROUP
         lib = N.load()
-        arr = _as_array(self.E, bases, group)
+        arr = _as_array(self.E, bases, TASK_GROUP[task])
+        slot, high_priority = self._TASK_SLOT[task]
         first, cnt = 0, 0  # 0, 0 = all windows
-        rng = self._plan_range(arr)
+        rng = self._task_range(task)
         if rng is not None:
             # this rank's windows are known before the plan exists, so the plan (fixed-base table rows, workspace) is
             # created for that range only: 1/8 of the table memory and build time on 8 ranks
             first, cnt = rng
             if cnt == 0:
                 return arr, None
-            arr.window_range = (first, cnt)
-        handle = arr.plan(slot, precompute=self.precompute_keys, high_priority=high_priority, concurrent=True)
+            arr.slot_ranges[slot] = (first, cnt)
+        else:
+            arr.slot_ranges.pop(slot, None)
+        handle = arr.plan(slot, precompute=self.precompute_keys, high_priority=high_priority, concurrent=True,
+                          window_bits=self._task_bits.get(task, 0))
         if wait_event is not None:
             N.check(lib.zk_msm_plan_wait_event(handle, wait_event))   # the scalars are still being produced on another stream
         if share_sort_of is not None and count == len(arr) and not os.environ.get("ZKMI_NO_SHARED_SORT"):
             # <tau_1, v> is already in flight with the same scalars: B2 = <tau_2, v> reuses its digits and sorted entries
+            # (refused, and sorted normally, when the two plans hold different window ranges)
             if lib.zk_msm_plan_enqueue_shared(handle, share_sort_of, N.STREAM_PLAN) == N.ZK_OK:
                 self._live.append(handle)
                 return arr, handle
@@ -245,24 +327,46 @@ class Groth16:
                 self._live.remove(handle)
         return out
 
-    def _exchange(self, parts):
-        """parts: [(limbs, group)] partial points of this rank -> totals over all ranks, as points"""
+    def _points(self, parts):
         from .._algebra import _point_class
         cid = self.E.curve.curve_id
-        if self._shard is not None and self._shard[1] > 1:
-            import time
-            from ..parallel import all_gather_limbs, sum_points
-            flat = np.concatenate([p for p, _ in parts])
-            t0 = time.perf_counter()
-            gathered = all_gather_limbs(flat, self._shard[2])  # (world, len)
-            self._collective_ms += (time.perf_counter() - t0) * 1e3
-            totals, off = [], 0
-            for p, group in parts:
-                totals.append(sum_points(cid, group, list(gathered[:, off:off + p.shape[0]])))
-                off += p.shape[0]
-        else:
-            totals = [p for p, _ in parts]
-        return [_point_class(cid, group)._from_limbs(t) for t, (_, group) in zip(totals, parts)]
+        return [_point_class(cid, group)._from_limbs(t) for t, group in parts]
+
+    # flag word that travels with the partial points: 0 = fine, 1 = this rank's witness check failed (a_i b_i != c_i somewhere),
+    # 2 = this rank failed otherwise.  Every rank learns of a failure in the SAME collective it would have waited in, and
+    # raises too, instead of hanging in all_gather while the failing rank has left prove() (round-3 advisor finding).
+    _FLAG_OK, _FLAG_WITNESS, _FLAG_ERROR = 0, 1, 2
+
+    def _exchange(self, parts, flag=0):
+        """parts: [(limbs, group)] partial points of this rank (zeros for MSMs it holds no window of) -> totals over all
+        ranks; one all_gather.  Raises on every rank when any rank reports a failure."""
+        import time
+        from ..parallel import all_gather_limbs, sum_points
+        cid = self.E.curve.curve_id
+        flat = np.concatenate([p for p, _ in parts] + [np.array([flag], dtype=np.uint64)])
+        t0 = time.perf_counter()
+        self._exchanged = True
+        gathered = all_gather_limbs(flat, self._shard[2])  # (world, len)
+        self._collective_ms += (time.perf_counter() - t0) * 1e3
+        flags = gathered[:, -1]
+        if (flags == self._FLAG_WITNESS).any():
+            raise ValueError("Failed to evaluate with the given witness")
+        if flags.any():
+            raise RuntimeError(f"Groth16.prove failed on rank(s) {[int(r) for r in np.nonzero(flags)[0]]}")
+        totals, off = [], 0
+        for p, group in parts:
+            totals.append((sum_points(cid, group, list(gathered[:, off:off + p.shape[0]])), group))
+            off += p.shape[0]
+        return self._points(totals)
+
+    def _report_failure(self, flag):
+        """a sharded rank that fails before the collective still takes part in it, with its flag set (points all zero)"""
+        cid = self.E.curve.curve_id
+        zeros = [(np.zeros(N.point_limbs(cid, g), dtype=np.uint64), g) for g in (1, 2, 1, 1, 1)]
+        try:
+            self._exchange(zeros, flag)
+        except (ValueError, RuntimeError):
+            pass   # the flag we just sent; the caller re-raises the original exception
 
     def prove(self, public_witness, private_witness) -> Proof:
         """public_witness / private_witness: lists of ints (reference API) or (k, 4) uint64 limb arrays."""
@@ -293,7 +397,7 @@ class Groth16:
             # <kdelta_1, w_priv> needs the witness only: it starts on its plan's stream as soon as the witness is in
             # HBM and runs beside the QAP transform chain
             if n_priv > 0:
-                pk.kdelta_1, early["k"] = self._enqueue_msm(pk.kdelta_1, 1, d_witness.ptr + 32 * n_pub, n_priv)
+                pk.kdelta_1, early["k"] = self._enqueue_msm(pk.kdelta_1, "k", d_witness.ptr + 32 * n_pub, n_priv)
 
         ordered = not os.environ.get("ZKMI_UNORDERED_MSMS")
         n_rows = self.qap.a.n_row
@@ -301,26 +405,33 @@ class Groth16:
         def start_uv_sorts(event, d_u, d_v):
             # u and v are final a third of the way into the QAP chain: the sorts of <tau_1, v> and <tau_1, u> run beside
             # the rest of it instead of in a phase of their own afterwards
-            pk.tau_1, early["v1"] = self._enqueue_msm(pk.tau_1, 1, d_v.ptr, min(n_rows, len(pk.tau_1)), slot=1, sort_only=True, wait_event=event)
-            pk.tau_1, early["u"] = self._enqueue_msm(pk.tau_1, 1, d_u.ptr, min(n_rows, len(pk.tau_1)), slot=0, sort_only=True, wait_event=event)
+            pk.tau_1, early["v1"] = self._enqueue_msm(pk.tau_1, "v1", _ptr(d_v), min(n_rows, len(pk.tau_1)), sort_only=True, wait_event=event)
+            pk.tau_1, early["u"] = self._enqueue_msm(pk.tau_1, "u", _ptr(d_u), min(n_rows, len(pk.tau_1)), sort_only=True, wait_event=event)
 
         # A plan accepts one run at a time: whatever goes wrong between the first enqueue and the last finish (a witness that
         # fails the divisibility check, an allocation failure, a HIP error, KeyboardInterrupt), the runs still in flight are
         # cancelled before the exception leaves, or every later prove() on this key would fail with "already has a run in flight"
         self._live = []
+        sharded = self._shard is not None and self._shard[1] > 1
+        self._exchanged = not sharded
         try:
             try:
-                res = self.qap.evaluate_witness_device(witness, after_upload=start_witness_msm, after_uv=start_uv_sorts if ordered else None)
+                res = self.qap.evaluate_witness_device(witness, after_upload=start_witness_msm, after_uv=start_uv_sorts if ordered else None,
+                                                       needs=self._qap_needs())
             except ValueError as exc:
                 raise ValueError("Failed to evaluate with the given witness") from exc
             return self._prove_msms(pk, res, early, ordered, r, s, q, t_start)
-        except BaseException:
+        except BaseException as exc:
             lib = N.load()
             for handle in self._live:
                 lib.zk_msm_plan_cancel(handle)   # status ignored: the original exception is the one to report
+            if not self._exchanged:
+                # the other ranks are (or will be) waiting in the proof's one collective: meet them there with the flag set
+                self._report_failure(self._FLAG_WITNESS if isinstance(exc, ValueError) else self._FLAG_ERROR)
             raise
         finally:
             self._live = []
+            self._exchanged = True
 
     def _prove_msms(self, pk, res, early, ordered, r, s, q, t_start):
         import time
@@ -334,17 +445,18 @@ class Groth16:
         # the last overlaps the next plan's accumulate kernel.
         if ordered:
             h_v1, h_u = early.get("v1"), early.get("u")   # sorts enqueued beside the QAP chain
-            pk.target_1, h_h = self._enqueue_msm(pk.target_1, 1, res.h.ptr, min(n, len(pk.target_1)), sort_only=True)
+            pk.target_1, h_h = self._enqueue_msm(pk.target_1, "h", _ptr(res.h),
+                                                 min(n, len(pk.target_1)), sort_only=True)
         else:
-            pk.tau_1, h_v1 = self._enqueue_msm(pk.tau_1, 1, res.v.ptr, min(n, len(pk.tau_1)), slot=1)
-        pk.tau_2, h_v2 = self._enqueue_msm(pk.tau_2, 2, res.v.ptr, min(n, len(pk.tau_2)), high_priority=True, share_sort_of=h_v1)
+            pk.tau_1, h_v1 = self._enqueue_msm(pk.tau_1, "v1", _ptr(res.v), min(n, len(pk.tau_1)))
+        pk.tau_2, h_v2 = self._enqueue_msm(pk.tau_2, "v2", _ptr(res.v), min(n, len(pk.tau_2)), share_sort_of=h_v1)
         if ordered:
             self._enqueue_rest(h_v1, h_v2)
             self._enqueue_rest(h_u, h_v1 or h_v2)
             self._enqueue_rest(h_h, h_u or h_v1 or h_v2)
         else:
-            pk.tau_1, h_u = self._enqueue_msm(pk.tau_1, 1, res.u.ptr, min(n, len(pk.tau_1)), slot=0)
-            pk.target_1, h_h = self._enqueue_msm(pk.target_1, 1, res.h.ptr, min(n, len(pk.target_1)))
+            pk.tau_1, h_u = self._enqueue_msm(pk.tau_1, "u", _ptr(res.u), min(n, len(pk.tau_1)))
+            pk.target_1, h_h = self._enqueue_msm(pk.target_1, "h", _ptr(res.h), min(n, len(pk.target_1)))
         h_k = early.get("k")
         t_enq = time.perf_counter()
         # the blinding terms depend on the key and (r, s) only: the host computes them (four scalar multiplications,
@@ -361,14 +473,14 @@ class Groth16:
         if self._shard is None or self._shard[1] <= 1:
             # A, B and the two scalar multiplications of C need <tau, u> and <tau, v> only: done on the host while the GPU
             # still works on <target_1, h>, the last MSM of the chain
-            msm_u, msm_v2, msm_v1, sum_delta_witness = self._exchange([(f_u, 1), (f_v2, 2), (f_v1, 1), (f_k, 1)])
+            msm_u, msm_v2, msm_v1, sum_delta_witness = self._points([(f_u, 1), (f_v2, 2), (f_v1, 1), (f_k, 1)])
             A = msm_u + a_fixed
             B1 = msm_v1 + b1_fixed
             B2 = msm_v2 + b2_fixed
             c_partial = sum_delta_witness + A * s + B1 * r + c_fixed
             f_h = self._finish_msm(h_h, 1)
             t_fin = time.perf_counter()
-            (HZ,) = self._exchange([(f_h, 1)])
+            (HZ,) = self._points([(f_h, 1)])
             C = HZ + c_partial
         else:
             f_h = self._finish_msm(h_h, 1)

@@ -55,10 +55,16 @@ class QAP:
     def _curve_id(self):
         return POLY_OBJECT[self.p].curve_id
 
-    def _device_matrices(self):
+    def _device_matrices(self, needs=None):
+        """the CSR matrices A, B, C in HBM (built on first use).  needs: the outputs the caller will ask for (a subset of
+        {"u", "v", "h"}; None = all): a rank that only ever needs u uploads A alone."""
         if self._dev is None:
-            from ..spmv import DeviceCsr
-            self._dev = [DeviceCsr(self._curve_id(), *m.to_csr()) for m in (self.a, self.b, self.c)]
+            self._dev = [None, None, None]
+        want = (True, True, True) if needs is None or "h" in needs else ("u" in needs, "v" in needs, False)
+        from ..spmv import DeviceCsr
+        for k, m in enumerate((self.a, self.b, self.c)):
+            if want[k] and self._dev[k] is None:
+                self._dev[k] = DeviceCsr(self._curve_id(), *m.to_csr())
         return self._dev
 
     def _workspace(self, n, n_col):
@@ -82,13 +88,17 @@ class QAP:
             self._stream = st
         return self._stream
 
-    def evaluate_witness_device(self, witness, after_upload=None, after_uv=None) -> DeviceQapResult:
+    def evaluate_witness_device(self, witness, after_upload=None, after_uv=None, needs=None) -> DeviceQapResult:
         """witness: list of ints or (n_col, 4) uint64 limbs.  Raises ValueError when the witness does
         not satisfy the constraints (non-zero remainder), like the reference.  The returned buffers belong
         to this QAP object and are overwritten by the next call.  `after_upload(witness_buffer)` is called once the
         canonical witness is resident in HBM, before the transform chain is enqueued.  `after_uv(event, u, v)` is called
         with the chain in flight: `event` fires when the coefficient vectors u and v (device buffers) are final, a third
-        of the way into the chain, so that work that needs only them can be queued behind it."""
+        of the way into the chain, so that work that needs only them can be queued behind it.
+        needs (a rank of a task-partitioned prover, Groth16.shard_over_ranks): the outputs that will be read, a subset of
+        {"u", "v", "h"}; None or anything with "h" runs the whole chain.  Without "h" only the sparse products and inverse
+        transforms behind u and / or v run (the other fields of the result are None) and the witness is NOT checked against the
+        constraints here -- the ranks that hold h do that."""
         lib = N.ensure_gpu()
         cid = self._curve_id()
         n = self.a.n_row
@@ -128,6 +138,21 @@ class QAP:
             N.check(lib.zk_stream_synchronize(st))
         if after_upload is not None:
             after_upload(ws["w"])
+        if needs is not None and "h" not in needs:
+            mats = self._device_matrices(needs)
+            d_u = ws["a"] if "u" in needs else None
+            d_v = ws["b"] if "v" in needs else None
+            if d_u is not None:
+                mats[0].apply(ws["w"].ptr, d_u.ptr, st)
+            if d_v is not None:
+                mats[1].apply(ws["w"].ptr, d_v.ptr, st)
+            if d_u is not None or d_v is not None:
+                event = N._vp()
+                N.check(lib.zk_qap_uv_dev(cid, log_n, d_u.ptr if d_u else None, d_v.ptr if d_v else None, st, N.ctypes.byref(event)))
+                if after_uv is not None:
+                    after_uv(event, d_u, d_v)
+                N.check(lib.zk_stream_synchronize(st))
+            return DeviceQapResult(n, d_u, d_v, None, ws["w"])
         for mat, dst in zip(self._device_matrices(), (ws["a"], ws["b"], ws["c"])):
             mat.apply(ws["w"].ptr, dst.ptr, st)
         ok = N._i(0)
