@@ -210,10 +210,24 @@ __global__ void twiddle9_kernel(uint32_t* out, Fp<P> zeta, uint32_t count) {
 // Element formats: the first pass reads canonical 8-word elements, the last pass writes them (multiplied by `scale` when
 // use_scale != 0: 1/N of the inverse transform); between two passes the elements travel as nine raw limb words with values
 // below 9p (in_raw / out_raw), see the range notes above.
+// What a pass can take on from the kernels around a transform (the QAP chain, qap_h_dev_impl):
+//   first pass   in_v / in_w != nullptr: the element is not read but FORMED, (in[p] * in_v[p] - in_w[p]) * z with z given as z R^2
+//                (the point-wise quotient of the coset evaluations; canonical inputs);
+//   last pass    scale_tab != nullptr: the output is multiplied by scale_tab[index] (canonical Montgomery representatives, 8
+//                words: g^i / N or g^-i / N -- the coset shift rides on the product the inverse transform pays for 1/N anyway);
+//                with out2 != nullptr that goes to out2 and `out` still receives x * scale (u and u g^i from one pass).
+struct NttFuse {
+    const uint32_t* in_v = nullptr;
+    const uint32_t* in_w = nullptr;
+    const uint32_t* scale_tab = nullptr;
+    uint32_t* out2 = nullptr;
+};
+
 template <class P>
 __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(const uint32_t* in, uint32_t* out,
                                                                const uint32_t* __restrict__ tw, int log_n,
-                                                               int rem, int m, int q, int in_raw, int final_pass, Fp<P> scale, int use_scale) {
+                                                               int rem, int m, int q, int in_raw, int final_pass, Fp<P> scale, int use_scale,
+                                                               NttFuse fuse, Fp<P> zq) {
     constexpr int N = P::N;  // register limbs (LDS is limb-major)
     constexpr int W = P::W;  // words per canonical element in HBM
     constexpr int T = TW_WORDS;
@@ -228,12 +242,30 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(c
     // bit-reversed digit (stride 2^q elements over the TOP five bits of the lane group), which would otherwise hit one bank
     const int pad_shift = tile_log >= 10 ? tile_log - 5 : 31;
     const uint32_t row = tile + 32;
-#define LIDX(e) ((e) + ((e) >> pad_shift))
+    // ... and bits 3-4 XORed with bits 5-6: a radix-4 step on element bits (3, 4) -- the last step of a pass with q = 3 -- reads
+    // and writes 8 consecutive elements per 8 lanes at a stride of 32 elements, four lane groups on the same 8 banks (4-way
+    // conflicts: 37.5 % of the LDS-active cycles of the first and last pass of a 2^22 transform,
+    // profiles/r04_ntt_lds_counters_baseline.json); with the swizzle the four groups land on four different bank octets, and
+    // every other access pattern of the kernel keeps bits 5-6 constant within a 32-lane group
+    const uint32_t swz = tile_log >= 7 ? 3u : 0u;
+#define LIDX(e) ((((e) ^ ((((e) >> 5) & swz) << 3))) + ((e) >> pad_shift))
 
     for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
         const uint32_t d = e >> q, r = e & qmask;
         const uint32_t p = (d << rest_bits) | rest0 | r;
-        Fp<P> x = in_raw ? load_limbs9<P>(in + (size_t)p * T) : load_fr<P>(in + (size_t)p * W);
+        Fp<P> x;
+        if (in_raw) {
+            x = load_limbs9<P>(in + (size_t)p * T);
+        } else if (fuse.in_v) {
+            // (u v - w) z as Montgomery products of canonical integers: mont(u, v) = u v / R, mont(w, 1) = w / R, mont(., z R^2)
+            Fp<P> one = fp_zero<P>();
+            one.v[0] = 1;
+            const Fp<P> d = fp_sub<P>(fp_mul<P>(load_fr<P>(in + (size_t)p * W), load_fr<P>(fuse.in_v + (size_t)p * W)),
+                                      fp_mul<P>(load_fr<P>(fuse.in_w + (size_t)p * W), one));
+            x = fp_mul<P>(d, zq);   // < 2p, normalised
+        } else {
+            x = load_fr<P>(in + (size_t)p * W);
+        }
         const uint32_t le = LIDX(e);
 #pragma unroll
         for (int l = 0; l < N; ++l) lds[l * row + le] = x.v[l];
@@ -281,6 +313,11 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(c
             const uint32_t j1 = j0 + ((1u << (b - 1)) << (rem - m));                    // stage s, bit b-1 set
             const uint32_t j2 = ((d0 & ((1u << (b - 1)) - 1)) << (rem - m)) | low;      // stage s-1 (both pairs)
             const uint32_t l00 = LIDX(e00), l01 = LIDX(e01), l10 = LIDX(e10), l11 = LIDX(e11);
+            // the three twiddles first: their loads travel while the tile elements come out of LDS (left where they were used,
+            // each load sat directly in front of its product with a full memory latency exposed, three times per step)
+            const Fp<P> w0 = load_limbs9<P>(tw_hi + (size_t)j0 * T);
+            const Fp<P> w1 = load_limbs9<P>(tw_hi + (size_t)j1 * T);
+            const Fp<P> w2 = load_limbs9<P>(tw_lo + (size_t)j2 * T);
             Fp<P> x00, x01, x10, x11;
 #pragma unroll
             for (int l = 0; l < N; ++l) {
@@ -289,11 +326,10 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(c
             }
             // stage s: (x00, x10) and (x01, x11); every input normalised and < 9p (range notes above)
             Fp<P> a0 = lz_add<P>(x00, x10);
-            Fp<P> a1 = fp_mul<P>(load_limbs9<P>(tw_hi + (size_t)j0 * T), lz_sub<P, 18, 29>(x00, x10));
+            Fp<P> a1 = fp_mul<P>(w0, lz_sub<P, 18, 29>(x00, x10));
             Fp<P> b0 = lz_add<P>(x01, x11);
-            Fp<P> b1 = fp_mul<P>(load_limbs9<P>(tw_hi + (size_t)j1 * T), lz_sub<P, 18, 29>(x01, x11));
+            Fp<P> b1 = fp_mul<P>(w1, lz_sub<P, 18, 29>(x01, x11));
             // stage s-1: (a0, b0) and (a1, b1), one twiddle
-            const Fp<P> w2 = load_limbs9<P>(tw_lo + (size_t)j2 * T);
             x00 = lz_reduce<P, 8>(lz_add<P>(a0, b0));
             x01 = fp_mul<P>(w2, lz_sub<P, 36, 30>(a0, b0));
             x10 = lz_norm<P>(lz_add<P>(a1, b1));
@@ -304,7 +340,13 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(c
                 lds[l * row + l10] = x10.v[l]; lds[l * row + l11] = x11.v[l];
             }
         }
-        __syncthreads();
+        // A step on element bits (pos_lo, pos_lo + 1) with pos_lo <= 6 stays inside blocks of 256 consecutive elements, and with
+        // one element quad per lane (tile / 4 == NTT_THREADS) wave w holds exactly block w: when this step and the next are both of
+        // that kind the next one reads only what this wave wrote, and the LDS serves one wave's accesses in order -- no workgroup
+        // barrier, the waves drift apart for two steps (the last two steps of a pass with q = 3)
+        const bool wave_private = (tile >> 2) == NTT_THREADS && pos_lo <= 6 && b >= 3;
+        if (wave_private) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        else __syncthreads();
     }
 
     const uint32_t fin_mask = done >= 32 ? 0xFFFFFFFFu : ((1u << done) - 1);
@@ -323,8 +365,19 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(c
         if (final_pass) {
             // 1/N of the inverse transform rides on a product (9 * 1 <= R/p: the result is below 2p); a forward transform
             // comes down from < 9p by an estimated multiple of 2p
-            x = use_scale ? fp_reduce_full<P>(fp_mul<P>(x, scale)) : lz_canonical<P>(x);
-            store_fr<P>(out + (size_t)po * W, x);
+            if (fuse.scale_tab) {
+                // x < 9p times a canonical constant: 9 * 1 <= R/p, the product is below 2p
+                const Fp<P> t = load_fr<P>(fuse.scale_tab + (size_t)po * W);
+                if (fuse.out2) {
+                    store_fr<P>(fuse.out2 + (size_t)po * W, fp_reduce_full<P>(fp_mul<P>(x, t)));
+                    store_fr<P>(out + (size_t)po * W, fp_reduce_full<P>(fp_mul<P>(x, scale)));
+                } else {
+                    store_fr<P>(out + (size_t)po * W, fp_reduce_full<P>(fp_mul<P>(x, t)));
+                }
+            } else {
+                x = use_scale ? fp_reduce_full<P>(fp_mul<P>(x, scale)) : lz_canonical<P>(x);
+                store_fr<P>(out + (size_t)po * W, x);
+            }
         } else {
             store_limbs9<P>(out + (size_t)po * T, x);
         }
@@ -581,8 +634,18 @@ static void free_scratch() {
 // per butterfly).  2^22 = 7 + 7 + 8 stages on tiles of 128 x 16, 128 x 16 and 256 x 8 elements: every global access is a
 // run of 256 or 512 bytes.  Data flow: d -> scratch A -> scratch B -> ... -> d (a single pass runs in place: one
 // workgroup holds the whole vector).
+// what qap_h_dev_impl folds into a transform: NttFuse for the kernel, plus the vectors the first pass reads from (src, instead
+// of d) and the last pass writes to (dst, instead of d)
 template <class P>
-static int ntt_dev_impl(int curve, int inverse, int log_n, uint32_t* d, hipStream_t stream) {
+struct NttPlanFuse {
+    const uint32_t* src = nullptr;
+    uint32_t* dst = nullptr;
+    NttFuse k;
+    Fp<P> zq;
+};
+
+template <class P>
+static int ntt_dev_impl(int curve, int inverse, int log_n, uint32_t* d, hipStream_t stream, const NttPlanFuse<P>* fuse = nullptr) {
     if (log_n < 0 || log_n > P::TWO_ADICITY || log_n > 30) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
     if (log_n == 0) return ZK_OK;
     static bool attr_set = false;
@@ -606,7 +669,8 @@ static int ntt_dev_impl(int curve, int inverse, int log_n, uint32_t* d, hipStrea
     uint32_t* scratch = nullptr;
     if (passes > 1 && (rc = get_scratch(stream, bytes * (passes > 2 ? 2 : 1), &scratch))) return rc;
     uint32_t* bufs[2] = {scratch, scratch ? scratch + (bytes / 4) : nullptr};
-    const uint32_t* src = d;
+    const uint32_t* src = fuse && fuse->src ? fuse->src : d;
+    uint32_t* final_dst = fuse && fuse->dst ? fuse->dst : d;
     int rem = log_n, which = 0;
     // Stages per pass.  An odd count costs a radix-2 step (616 instructions for one stage of four elements against 1054 for the two
     // stages of a radix-4 step), so odd digits are paired up into even ones where the sum allows it, and the smallest digit goes in
@@ -634,11 +698,14 @@ static int ntt_dev_impl(int curve, int inverse, int log_n, uint32_t* d, hipStrea
         const int rest_bits = log_n - m;
         const int q = passes == 1 ? 0 : std::min(NTT_TILE_LOG - m, rest_bits);
         const bool last = i == passes - 1;
-        uint32_t* dst = last ? d : bufs[which];
+        uint32_t* dst = last ? final_dst : bufs[which];
         const uint32_t tile = 1u << (m + q);
         const size_t lds_bytes = (size_t)P::N * (tile + 32) * 4;
+        NttFuse kf;
+        if (fuse && i == 0) { kf.in_v = fuse->k.in_v; kf.in_w = fuse->k.in_w; }
+        if (fuse && last) { kf.scale_tab = fuse->k.scale_tab; kf.out2 = fuse->k.out2; }
         hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(1u << (rest_bits - q)), dim3(NTT_THREADS), lds_bytes, stream, src, dst, tw, log_n, rem, m, q,
-                           i > 0 ? 1 : 0, last ? 1 : 0, scale, (last && inverse) ? 1 : 0);
+                           i > 0 ? 1 : 0, last ? 1 : 0, scale, (last && inverse) ? 1 : 0, kf, fuse ? fuse->zq : fp_zero<P>());
         src = dst;
         which ^= 1;
         rem -= m;
@@ -760,10 +827,12 @@ struct CosetTables {
     uint32_t *lo = nullptr, *hi = nullptr, *lo_inv = nullptr, *hi_inv = nullptr;
 };
 static std::map<int, CosetTables> g_coset;  // per curve (under g_tw_mutex)
+static void free_coset_scale_tabs();
 static void free_coset_tables() {  // caller holds g_tw_mutex
     for (auto& kv : g_coset)
         for (uint32_t* p : {kv.second.lo, kv.second.hi, kv.second.lo_inv, kv.second.hi_inv}) (void)hipFree(p);
     g_coset.clear();
+    free_coset_scale_tabs();
 }
 
 template <class P>
@@ -792,6 +861,45 @@ static int get_coset_tables(int curve, CosetTables* out, hipStream_t stream) {
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipStreamSynchronize(stream));
     g_coset[curve] = t;
+    *out = t;
+    return ZK_OK;
+}
+
+// tab[i] = g^(+-i) / N as canonical Montgomery representatives (8 words): what the last pass of an inverse transform multiplies
+// by when the coset shift is folded into it (NttFuse::scale_tab)
+template <class P>
+__global__ void coset_scale_tab_kernel(uint32_t* __restrict__ tab, uint64_t n, const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi,
+                                       Fp<P> inv_n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp<P> t = fp_mul<P>(load_fr<P>(lo + (size_t)(i & ((1u << COSET_SPLIT) - 1)) * P::W), load_fr<P>(hi + (size_t)(i >> COSET_SPLIT) * P::W));
+    t = fp_mul<P>(t, inv_n);   // (g^i R)(R/N)/R
+    store_fr<P>(tab + i * P::W, fp_reduce_full<P>(t));
+}
+
+struct CosetScaleTabs {
+    uint32_t *fwd = nullptr, *inv = nullptr;   // g^i / N, g^-i / N
+};
+static std::map<std::pair<int, int>, CosetScaleTabs> g_coset_scale;   // (curve, log_n), under g_tw_mutex
+
+template <class P>
+static int get_coset_scale_tabs(int curve, int log_n, const CosetTables& ct, CosetScaleTabs* out, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_tw_mutex);
+    auto it = g_coset_scale.find({curve, log_n});
+    if (it != g_coset_scale.end()) { *out = it->second; return ZK_OK; }
+    const uint64_t n = 1ull << log_n;
+    CosetScaleTabs t;
+    ZK_HIP(hipMalloc(&t.fwd, n * P::W * 4));
+    ZK_HIP(hipMalloc(&t.inv, n * P::W * 4));
+    uint32_t nn[P::W] = {0};
+    nn[0] = (uint32_t)n;   // log_n <= 30 (ntt_dev_impl refuses more)
+    const Fp<P> inv_n = fp_inv<P>(fp_from_canonical<P>(nn));   // Montgomery form of 1/N
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(coset_scale_tab_kernel<P>, dim3(blocks), dim3(256), 0, stream, t.fwd, n, ct.lo, ct.hi, inv_n);
+    hipLaunchKernelGGL(coset_scale_tab_kernel<P>, dim3(blocks), dim3(256), 0, stream, t.inv, n, ct.lo_inv, ct.hi_inv, inv_n);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(stream));
+    g_coset_scale[{curve, log_n}] = t;
     *out = t;
     return ZK_OK;
 }
@@ -833,6 +941,11 @@ __global__ void qap_quotient_kernel(uint64_t n, const uint32_t* __restrict__ u, 
     store_fr<P>(out + i * P::W, fp_reduce_full<P>(fp_mul<P>(d, z_r2)));
 }
 
+static void free_coset_scale_tabs() {  // caller holds g_tw_mutex
+    for (auto& kv : g_coset_scale) { (void)hipFree(kv.second.fwd); (void)hipFree(kv.second.inv); }
+    g_coset_scale.clear();
+}
+
 static std::mutex g_uv_mutex;
 static std::map<hipStream_t, hipEvent_t> g_uv_events;  // one "u and v are final" event per stream (zk_qap_h_dev_begin)
 
@@ -859,7 +972,7 @@ static int qap_h_dev_impl(int curve, int log_n, uint32_t* a_u, uint32_t* b_v, co
                           uint32_t* work, int* divisible, hipStream_t stream, hipEvent_t uv_ready = nullptr) {
     if (log_n > P::TWO_ADICITY) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
     const uint64_t n = 1ull << log_n;
-    const size_t eb = P::W * 4;
+
     const unsigned blocks = (unsigned)((n + 255) / 256);
     uint32_t* W0 = work;                     // w coefficients, then w on the coset
     uint32_t* U1 = work + n * P::W;          // u on the coset, then the quotient's coset values
@@ -868,16 +981,25 @@ static int qap_h_dev_impl(int curve, int log_n, uint32_t* a_u, uint32_t* b_v, co
     CosetTables ct;
     int rc;
     if ((rc = get_coset_tables<P>(curve, &ct, stream))) return rc;
+    CosetScaleTabs st;
+    if (log_n > 30) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
+    if ((rc = get_coset_scale_tabs<P>(curve, log_n, ct, &st, stream))) return rc;
     ZK_HIP(hipMemsetAsync(dflag, 0, sizeof(int), stream));
     hipLaunchKernelGGL(qap_eval_check_kernel<P>, dim3(blocks), dim3(256), 0, stream, n, a_u, b_v, c, dflag);
-    if ((rc = ntt_dev_impl<P>(curve, 1, log_n, a_u, stream))) return rc;  // u
-    if ((rc = ntt_dev_impl<P>(curve, 1, log_n, b_v, stream))) return rc;  // v
+    // Seven transforms and nothing between them (round 4): the coset shift g^i rides on the 1/N product of the inverse
+    // transforms' last pass (u and v leave it twice: plain, for their MSMs, and shifted), w is read from c and written shifted,
+    // the point-wise quotient is formed by the first pass of the last inverse transform as it loads, and that transform's last
+    // pass multiplies by g^-i / N and writes h.  Before: four coset_mul launches, one quotient launch and a copy of c.
+    NttPlanFuse<P> f;
+    f.k.scale_tab = st.fwd;
+    f.k.out2 = U1;
+    if ((rc = ntt_dev_impl<P>(curve, 1, log_n, a_u, stream, &f))) return rc;  // u, and u g^i into U1
+    f.k.out2 = V1;
+    if ((rc = ntt_dev_impl<P>(curve, 1, log_n, b_v, stream, &f))) return rc;  // v, and v g^i into V1
     if (uv_ready) ZK_HIP(hipEventRecord(uv_ready, stream));
-    ZK_HIP(hipMemcpyAsync(W0, c, n * eb, hipMemcpyDeviceToDevice, stream));
-    if ((rc = ntt_dev_impl<P>(curve, 1, log_n, W0, stream))) return rc;   // w
-    hipLaunchKernelGGL(coset_mul_kernel<P>, dim3(blocks), dim3(256), 0, stream, a_u, U1, n, ct.lo, ct.hi);
-    hipLaunchKernelGGL(coset_mul_kernel<P>, dim3(blocks), dim3(256), 0, stream, b_v, V1, n, ct.lo, ct.hi);
-    hipLaunchKernelGGL(coset_mul_kernel<P>, dim3(blocks), dim3(256), 0, stream, W0, W0, n, ct.lo, ct.hi);
+    f.k.out2 = nullptr;
+    f.src = c;
+    if ((rc = ntt_dev_impl<P>(curve, 1, log_n, W0, stream, &f))) return rc;   // w g^i, straight from c
     if ((rc = ntt_dev_impl<P>(curve, 0, log_n, U1, stream))) return rc;
     if ((rc = ntt_dev_impl<P>(curve, 0, log_n, V1, stream))) return rc;
     if ((rc = ntt_dev_impl<P>(curve, 0, log_n, W0, stream))) return rc;
@@ -885,10 +1007,13 @@ static int qap_h_dev_impl(int curve, int log_n, uint32_t* a_u, uint32_t* b_v, co
     Fp<P> gn = coset_generator<P>();
     for (int k = 0; k < log_n; ++k) gn = fp_sqr<P>(gn);
     Fp<P> z = fp_inv<P>(fp_sub<P>(gn, fp_one<P>()));          // Montgomery form: z R
-    Fp<P> z_r2 = fp_mul<P>(z, fp_const<P>(P::R2));            // z R * R^2 / R = z R^2
-    hipLaunchKernelGGL(qap_quotient_kernel<P>, dim3(blocks), dim3(256), 0, stream, n, U1, V1, W0, z_r2, U1);
-    if ((rc = ntt_dev_impl<P>(curve, 1, log_n, U1, stream))) return rc;
-    hipLaunchKernelGGL(coset_mul_kernel<P>, dim3(blocks), dim3(256), 0, stream, U1, h, n, ct.lo_inv, ct.hi_inv);
+    NttPlanFuse<P> fq;
+    fq.zq = fp_mul<P>(z, fp_const<P>(P::R2));                 // z R * R^2 / R = z R^2
+    fq.k.in_v = V1;
+    fq.k.in_w = W0;
+    fq.k.scale_tab = st.inv;
+    fq.dst = h;
+    if ((rc = ntt_dev_impl<P>(curve, 1, log_n, U1, stream, &fq))) return rc;  // h = iNTT((u v - w) z) g^-i
     ZK_HIP(hipGetLastError());
     if (!divisible) return ZK_OK;
     int flag = 0;
