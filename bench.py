@@ -208,10 +208,15 @@ def main():
         achieved = BYTES_PER_PAIR * n / acc_s / 1e9 if acc_s > 0 else 0.0
         # HBM bytes of one launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, tools/collect_profiles.sh); only reported
         # while the kernel sources are the ones it was measured on (tools/fingerprint.py)
-        from tools.fingerprint import load_traffic
+        from tools.fingerprint import load_profiled, load_traffic
         traffic, traffic_src = load_traffic("msm_traffic.json", "msm")
+        kernel_ms_profiled = load_profiled("msm_traffic.json", "msm", "kernel_avg_ms_profiled")
         if args.log_n != 20 or args.precompute or args.window_bits or world > 1:
-            traffic, traffic_src = None, "the committed figure is for the default 2^20 single-GPU run"
+            traffic, traffic_src, kernel_ms_profiled = None, "the committed figure is for the default 2^20 single-GPU run", None
+        # two fractions, because they answer different questions (round-3 advisor finding: one object carried both kinds of
+        # number): `frac` prices the ALGORITHMIC 96 B per pair (what the contract asks for), `frac_measured` the bytes the
+        # counters saw -- signed-digit Pippenger reads a base once per WINDOW, and a 64-byte row costs a 128-byte line
+        measured = traffic / acc_s / 1e9 if traffic and acc_s > 0 else None
         line = {
             "metric": "BN254 G1 MSM throughput",
             "value": round(value, 3),
@@ -248,7 +253,14 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "kernel_ms": round(float(stage[1]), 4),
-                "note": "254-bit modular arithmetic makes this kernel integer-VALU bound, not HBM bound; see DESIGN.md",
+                "kernel_ms_profiled": kernel_ms_profiled,
+                "achieved_measured": round(measured, 1) if measured else None,
+                "frac_measured": round(measured / HBM_PEAK_GBPS, 4) if measured else None,
+                "note": "achieved / frac: algorithmic bytes (96 B per pair) over the kernel's time, HIP events around its launches in this "
+                        "run (kernel_ms); kernel_ms_profiled: the same kernel's average in the rocprofv3 kernel trace of the same command "
+                        "(profiles/, same sources).  achieved_measured / frac_measured: the counters' bytes (`traffic`) over kernel_ms -- "
+                        "about half of the HBM peak: every base row is read once per window and costs a 128-byte line.  What binds is "
+                        "integer VALU issue (roofline_valu: the SIMDs are saturated, profiles/*_bench_pmc_sq.json); see DESIGN.md 4.1",
             },
             # the resource that actually binds: 32-bit integer multiply-add issue.  Per mixed addition the kernel
             # executes 8 products (2 N^2 = 162 v_mad_u64_u32 at N = 9 limbs, plus N v_mul_lo_u32) and 2 squarings (126); the

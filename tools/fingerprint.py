@@ -27,6 +27,18 @@ def source_fingerprint(which="msm"):
     return h.hexdigest()[:16]
 
 
+def load_profiled(name, which, key):
+    """another field of profiles/<name> (e.g. "kernel_avg_ms_profiled") under the same fingerprint rule, or None"""
+    import json
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        with open(path) as f:
+            tj = json.load(f)
+    except Exception:  # noqa: BLE001 - absent or unreadable: nothing to report
+        return None
+    return tj.get(key) if tj.get("source_fingerprint") == source_fingerprint(which) else None
+
+
 def load_traffic(name, which):
     """(bytes or None, source string): the figure of profiles/<name> if it was measured on the present sources"""
     import json

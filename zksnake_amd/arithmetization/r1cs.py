@@ -48,11 +48,8 @@ class FileConstraintSystem:
             wire = r.wire_names.index(target.name, 1)
         except ValueError:
             raise KeyError(f"unknown variable {target.name}") from None
-        args = tuple(args)
-        for a in args:
-            if a not in r._wire_of:
-                raise KeyError(f"Argument not exist: {a}")
-        self.hints.append((wire, func, args))
+        # the argument names are looked up when the hint is evaluated, as in the reference (symbolic.rs:760 "Argument not exist")
+        self.hints.append((wire, func, tuple(args)))
 
     def solve(self, inputs: dict) -> dict:
         return self._r1cs.solve(inputs)
@@ -178,6 +175,9 @@ class R1CS:
         def fire_hints(todo):
             fired, rest = False, []
             for wire, func, args in todo:
+                for a in args:
+                    if a not in self._wire_of:
+                        raise KeyError(f"Argument not exist: {a}")
                 vals = [w[self._wire_of[a]] for a in args]
                 if any(v is None for v in vals):
                     rest.append((wire, func, args))
@@ -187,6 +187,10 @@ class R1CS:
                     raise TypeError("Non deterministic result must be Integer")
                 if out < 0:
                     raise OverflowError("can't convert negative int to unsigned")   # the reference parses the result as BigUint
+                # A hint may confirm a wire that an input or the propagation has already fixed, never change it: the reference
+                # overwrites blindly (symbolic.rs:771-773), which lets a hint silently replace a declared input (round-3 advisor finding)
+                if w[wire] is not None and w[wire] != out % p:
+                    raise ValueError(f"hint for wire {wire} ({self.wire_names[wire]}) contradicts the value it already has")
                 w[wire] = out % p
                 fired = True
             return fired, rest

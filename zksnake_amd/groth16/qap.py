@@ -115,23 +115,27 @@ class QAP:
         st = self._qap_stream()
         row = 0
         staged_async = False
-        for part in parts:
-            if len(part) and not isinstance(part, np.ndarray):
-                # ints (the reference's call shape) are repacked into the page-locked staging rows, reduced mod r, and every
-                # finished chunk goes up on the QAP stream while the worker threads convert the next one
-                stage = ws["w_host"].array[row:row + len(part)]
-                base = ws["w"].ptr + 32 * row
+        try:
+            for part in parts:
+                if len(part) and not isinstance(part, np.ndarray):
+                    # ints (the reference's call shape) are repacked into the page-locked staging rows, reduced mod r, and every
+                    # finished chunk goes up on the QAP stream while the worker threads convert the next one
+                    stage = ws["w_host"].array[row:row + len(part)]
+                    base = ws["w"].ptr + 32 * row
 
-                def ship(b, e, stage=stage, base=base):
-                    N.check(lib.zk_dev_upload_async(base + 32 * b, stage[b:e].ctypes.data, 32 * (e - b), st))
+                    def ship(b, e, stage=stage, base=base):
+                        N.check(lib.zk_dev_upload_async(base + 32 * b, stage[b:e].ctypes.data, 32 * (e - b), st))
 
-                N.ints_to_limbs(part, 4, self.p, out=stage, chunk_done=ship)
-                staged_async = True
-            elif len(part):
-                ws["w"].upload(part, offset=32 * row)
-            row += len(part)
-        if staged_async:
-            N.check(lib.zk_stream_synchronize(st))   # the witness is resident before anything is queued against it
+                    staged_async = True   # before the conversion: a chunk may have been shipped when a later one raises
+                    N.ints_to_limbs(part, 4, self.p, out=stage, chunk_done=ship)
+                elif len(part):
+                    ws["w"].upload(part, offset=32 * row)
+                row += len(part)
+        finally:
+            # also when the conversion fails half way (a negative int in a later chunk): copies out of the shared staging buffer
+            # may still be in flight, and the next prove() rewrites that buffer (round-3 advisor finding)
+            if staged_async:
+                N.check(lib.zk_stream_synchronize(st))   # the witness is resident before anything is queued against it
         if any(isinstance(p, np.ndarray) for p in (witness if isinstance(witness, tuple) else (witness,))):
             # int lists were reduced mod r on the host (Fr::from); limb arrays are reduced here, one cheap pass
             N.check(lib.zk_vec_canon_dev(cid, self.a.n_col, ws["w"].ptr, st))
