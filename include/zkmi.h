@@ -176,6 +176,12 @@ int zk_qap_uv_dev(int curve, int log_n, void* d_a_u, void* d_b_v, void* stream, 
  * out = sum_i scalars[i] * bases[i].  n_scalars != n_points -> ZK_ERR_LENGTH. */
 int zk_msm(int curve, int group, uint64_t n_points, uint64_t n_scalars, const uint64_t* scalars,
            const uint64_t* bases, uint64_t* out);
+/* zk_msm is the reference's call shape and pays for it on every call: the bases go to the device and into Montgomery form, a
+ * workspace is built and torn down (2^20 BN254 G1 pairs: ~3.6 ms, of which the MSM itself is 1.5).  The library does NOT cache
+ * bases behind this entry point: recognising "the same array" by pointer and a hash of sampled rows would return a wrong point
+ * after an in-place change the samples miss, and hashing all 64 MB costs more than the MSM.  A caller that multiplies against the
+ * same points more than once (a proving key) creates a plan once -- zk_msm_plan_create below -- and calls zk_msm_plan_run; the
+ * Python layer does exactly that behind EllipticCurve.multiexp when it is handed a PointArray (zksnake_amd/_algebra.py). */
 
 /* batch_multi_scalar_g1 / _g2 (src/bn254/curve.rs:326-354): out[i] = scalars[i] * bases[i];
  * broadcast != 0 means `bases` holds one point used for every scalar (ecc.py:93-94). */
