@@ -307,6 +307,12 @@ int zk_point_bytes(int curve, int group);
 /* out = a*x + b*y + c (element-wise; b and d_y may both be NULL, c may be NULL); out may alias x or y */
 int zk_vec_axpby_dev(int curve, uint64_t n, const uint64_t* a, const void* d_x, const uint64_t* b, const void* d_y, const uint64_t* c,
                      void* d_out, void* stream);
+/* acc[i] += sum_{t<k} scalars[t] * x_t[i] for i < counts[t] (counts[t] <= n_acc), then acc[at_index[j]] += at_vals[j] for j < n_at: a chain
+ * of Polynomial scalar-multiply-adds and single-coefficient updates (plonk/protocol.py:319-402, :213-236 blinding) in ONE launch -- as
+ * separate launches of a few microseconds each they leave the GPU idle between them.  k <= 16, n_at <= 8; scalars / at_vals are 4-limb
+ * canonical integers in host memory, k * 4 and n_at * 4 limbs. */
+int zk_vec_lincomb_dev(int curve, uint64_t n_acc, void* d_acc, int k, const uint64_t* counts, const void* const* d_x, const uint64_t* scalars,
+                       int n_at, const uint64_t* at_index, const uint64_t* at_vals, void* stream);
 /* dst[i] = src[offset + i*stride], i < n: one column of the flat witness [a0, b0, c0, a1, ...] (protocol.py:167-169) */
 int zk_vec_gather_dev(int curve, uint64_t n, const void* d_src, uint64_t stride, uint64_t offset, void* d_dst, void* stream);
 /* *is_zero = 1 when all n elements are zero (synchronises the stream) */

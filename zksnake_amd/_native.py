@@ -110,6 +110,7 @@ SIGNATURES = {
     "zk_points_decompress": (_i, [_i, _i, _u64, _u8p, _u64p, _u64p]),
     "zk_point_bytes": (_i, [_i, _i]),
     "zk_vec_axpby_dev": (_i, [_i, _u64, _u64p, _vp, _u64p, _vp, _u64p, _vp, _vp]),
+    "zk_vec_lincomb_dev": (_i, [_i, _u64, _vp, _i, _u64p, ctypes.POINTER(_vp), _u64p, _i, _u64p, _u64p, _vp]),
     "zk_vec_gather_dev": (_i, [_i, _u64, _vp, _u64, _u64, _vp, _vp]),
     "zk_vec_is_zero_dev": (_i, [_i, _u64, _vp, ctypes.POINTER(_i), _vp]),
     "zk_poly_eval_dev": (_i, [_i, _u64, _vp, _u64p, _u64p, _vp]),

@@ -42,6 +42,31 @@ __global__ __launch_bounds__(256) void axpby_kernel(uint64_t n, Fp<P> a_m, const
     store_fr<P>(out + i * P::W, fp_reduce_full<P>(v));
 }
 
+// acc[i] += sum_k s_k x_k[i] (i < count_k), then acc[at_j] += c_j: a whole chain of scalar multiply-adds and single-coefficient
+// updates in ONE launch (the linearisation polynomial of a PlonK proof is ten such terms, a blinding two to three updates; as
+// separate launches of a few microseconds each they left the GPU idle between them: launch-bound)
+constexpr int LINCOMB_MAX_TERMS = 16, LINCOMB_MAX_AT = 8;
+template <class P>
+struct LincombArgs {
+    const uint32_t* x[LINCOMB_MAX_TERMS];
+    uint64_t count[LINCOMB_MAX_TERMS];
+    Fp<P> s_m[LINCOMB_MAX_TERMS];      // s R: mont(x, s R) = s x
+    uint64_t at[LINCOMB_MAX_AT];
+    Fp<P> at_val[LINCOMB_MAX_AT];      // canonical
+    int k, n_at;
+};
+template <class P>
+__global__ __launch_bounds__(256) void lincomb_kernel(uint64_t n, uint32_t* __restrict__ acc, LincombArgs<P> a) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp<P> v = load_fr<P>(acc + i * P::W);
+    for (int t = 0; t < a.k; ++t)
+        if (i < a.count[t]) v = fp_add<P>(v, fp_mul<P>(load_fr<P>(a.x[t] + i * P::W), a.s_m[t]));
+    for (int j = 0; j < a.n_at; ++j)
+        if (i == a.at[j]) v = fp_add<P>(v, a.at_val[j]);
+    store_fr<P>(acc + i * P::W, fp_reduce_full<P>(fp_reduce_full<P>(v)));
+}
+
 // out[i] = in[offset + i * stride]: de-interleaves the flat PlonK witness [a0, b0, c0, a1, ..] into its three columns
 template <class P>
 __global__ __launch_bounds__(256) void gather_kernel(uint64_t n, const uint4* __restrict__ in, uint64_t stride, uint64_t offset, uint4* __restrict__ out) {
@@ -370,6 +395,35 @@ static int axpby_impl(uint64_t n, const uint64_t* a, const void* x, const uint64
 }
 
 template <class P>
+static int lincomb_impl(uint64_t n_acc, void* acc, int k, const uint64_t* counts, const void* const* xs, const uint64_t* scalars, int n_at,
+                        const uint64_t* at_index, const uint64_t* at_vals, hipStream_t st) {
+    if (k < 0 || k > LINCOMB_MAX_TERMS || n_at < 0 || n_at > LINCOMB_MAX_AT) return fail(ZK_ERR_ARG, "lincomb: at most 16 terms and 8 single updates");
+    if (n_acc == 0 || (k == 0 && n_at == 0)) return ZK_OK;
+    if (!acc || (k && (!counts || !xs || !scalars)) || (n_at && (!at_index || !at_vals))) return fail(ZK_ERR_ARG, "lincomb: null argument");
+    LincombArgs<P> a;
+    a.k = k;
+    a.n_at = n_at;
+    uint64_t reach = 0;   // the launch only covers what some term or update touches
+    for (int t = 0; t < k; ++t) {
+        if (counts[t] > n_acc) return fail(ZK_ERR_ARG, "lincomb: a term is longer than the accumulator");
+        if (counts[t] && !xs[t]) return fail(ZK_ERR_ARG, "lincomb: null term");
+        a.x[t] = (const uint32_t*)xs[t];
+        a.count[t] = counts[t];
+        a.s_m[t] = scalar_times_r<P>(scalars + 4 * t, 1);
+        reach = std::max<uint64_t>(reach, counts[t]);
+    }
+    for (int j = 0; j < n_at; ++j) {
+        if (at_index[j] >= n_acc) return fail(ZK_ERR_ARG, "lincomb: update index beyond the accumulator");
+        a.at[j] = at_index[j];
+        a.at_val[j] = scalar_in<P>(at_vals + 4 * j);
+        reach = std::max<uint64_t>(reach, at_index[j] + 1);
+    }
+    hipLaunchKernelGGL(lincomb_kernel<P>, dim3((unsigned)((reach + 255) / 256)), dim3(256), 0, st, reach, (uint32_t*)acc, a);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+template <class P>
 static int is_zero_impl(uint64_t n, const void* x, int* is_zero, hipStream_t st) {
     *is_zero = 1;
     if (n == 0) return ZK_OK;
@@ -497,6 +551,13 @@ int zk_poly_eval_many_dev(int curve, int k, const uint64_t* counts, const void* 
 int zk_vec_axpby_dev(int curve, uint64_t n, const uint64_t* a, const void* d_x, const uint64_t* b, const void* d_y, const uint64_t* c,
                      void* d_out, void* stream) {
 #define CALL(P) return axpby_impl<P>(n, a, d_x, b, d_y, c, d_out, (hipStream_t)stream)
+    ZK_DISPATCH_FR(curve, CALL);
+#undef CALL
+}
+
+int zk_vec_lincomb_dev(int curve, uint64_t n_acc, void* d_acc, int k, const uint64_t* counts, const void* const* d_x, const uint64_t* scalars,
+                       int n_at, const uint64_t* at_index, const uint64_t* at_vals, void* stream) {
+#define CALL(P) return lincomb_impl<P>(n_acc, d_acc, k, counts, d_x, scalars, n_at, at_index, at_vals, (hipStream_t)stream)
     ZK_DISPATCH_FR(curve, CALL);
 #undef CALL
 }

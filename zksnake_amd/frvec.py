@@ -213,6 +213,24 @@ class FrOps:
         """acc[:n] += s * x[:n]"""
         N.check(N.load().zk_vec_axpby_dev(self.cid, n, N.u64p(self.one(1)), acc_ptr, N.u64p(self.one(s)), x_ptr, None, acc_ptr, None))
 
+    def d_lincomb(self, acc, terms=(), at=()):
+        """acc (a DevVec) += sum of s * x[:count] over terms [(count, s, device pointer)], then acc[i] += v over at [(i, v)]: one
+        launch for the whole chain (zk_vec_lincomb_dev: at most 16 terms and 8 single updates per call; longer lists are cut)"""
+        lib = N.load()
+        terms, at = list(terms), list(at)
+        while terms or at:
+            tk, terms = terms[:16], terms[16:]
+            ak, at = at[:8], at[8:]
+            k, n_at = len(tk), len(ak)
+            counts = np.array([t[0] for t in tk], dtype=np.uint64)
+            ptrs = (N._vp * max(k, 1))(*[t[2] for t in tk])
+            scalars = np.concatenate([self.one(t[1] % self.r) for t in tk]).reshape(k, 4) if k else np.zeros((1, 4), dtype=np.uint64)
+            idx = np.array([a[0] for a in ak], dtype=np.uint64)
+            vals = np.concatenate([self.one(a[1] % self.r) for a in ak]).reshape(n_at, 4) if n_at else np.zeros((1, 4), dtype=np.uint64)
+            N.check(lib.zk_vec_lincomb_dev(self.cid, acc.n, acc.ptr(), k, N.u64p(counts) if k else None, ptrs if k else None,
+                                           N.u64p(scalars) if k else None, n_at, N.u64p(idx) if n_at else None,
+                                           N.u64p(vals) if n_at else None, None))
+
     def d_is_zero(self, n, ptr):
         flag = ctypes.c_int(0)
         N.check(N.load().zk_vec_is_zero_dev(self.cid, n, ptr, ctypes.byref(flag), None))

@@ -189,10 +189,8 @@ class Plonk:
         return out
 
     def _blind(self, vec, n, scalars):
-        """vec += (s0 + s1 X + ..)(X^n - 1) on a device coefficient vector"""
-        for i, s in enumerate(scalars):
-            self._ops.d_add_at(vec, i, -s)
-            self._ops.d_add_at(vec, n + i, s)
+        """vec += (s0 + s1 X + ..)(X^n - 1) on a device coefficient vector: one launch for its four to six coefficient updates"""
+        self._ops.d_lincomb(vec, at=[(i, -s) for i, s in enumerate(scalars)] + [(n + i, s) for i, s in enumerate(scalars)])
 
     def prove(self, public_witness: dict, private_witness) -> Proof:
         """public_witness: {row: value}; private_witness: flat [a0, b0, c0, a1, ...] as ints or a (3k, 4) limb array."""
@@ -318,27 +316,27 @@ class Plonk:
         a2l1 = alpha * alpha * l1_zeta % r
 
         lin = DevVec(n + 6)
-        for k, weight in zip(SELECTORS, (za, zb, zc, za * zb % r, 1)):
-            V.d_axpy(n, lin.ptr(), weight, dev["q_coeffs"][k].ptr())
-        V.d_axpy(n + 3, lin.ptr(), (alpha * f1 + a2l1) % r, z.ptr())
-        V.d_axpy(n, lin.ptr(), -alpha * f2 * beta % r, sc[2].ptr())
         w_mid, w_hi = zh_zeta * zeta_n % r, zh_zeta * zeta_n * zeta_n % r
-        V.d_axpy(n, lin.ptr(), -zh_zeta % r, t.ptr())
-        V.d_axpy(n, lin.ptr(), -w_mid % r, t.ptr(n))
-        V.d_axpy(n + 6, lin.ptr(), -w_hi % r, t.ptr(2 * n))
+        # the ten terms of the linearisation polynomial in ONE launch (they were ten launches of a few microseconds each, with the
+        # GPU idle between them: the section was launch-bound)
+        V.d_lincomb(lin, [(n, weight, dev["q_coeffs"][k].ptr()) for k, weight in zip(SELECTORS, (za, zb, zc, za * zb % r, 1))]
+                    + [(n + 3, alpha * f1 + a2l1, z.ptr()), (n, -alpha * f2 * beta, sc[2].ptr()),
+                       (n, -zh_zeta, t.ptr()), (n, -w_mid, t.ptr(n)), (n + 6, -w_hi, t.ptr(2 * n))])
         for value in (za, zb, zc, zs1, zs2, zzw):
             transcript.append(value)
 
         # -- round 5: opening proofs --------------------------------------------------------------------
         v = transcript.get_challenge_scalar()
-        vk_pow, shift = 1, 0
+        vk_pow, shift, opening_terms = 1, 0, []
         for poly, count, value in ((wires[0], n + 2, za), (wires[1], n + 2, zb), (wires[2], n + 2, zc), (sc[0], n, zs1), (sc[1], n, zs2)):
             vk_pow = vk_pow * v % r
-            V.d_axpy(count, lin.ptr(), vk_pow, poly.ptr())
+            opening_terms.append((count, vk_pow, poly.ptr()))
             shift += vk_pow * value
-        # constant and X^n corrections: PI(zeta), the sigma_3 / L1 constants, the quotient blinding, the opening values
-        V.d_add_at(lin, 0, pi_zeta - alpha * f2 * (zc + gamma) - a2l1 + w_mid * blind[9] + w_hi * blind[10] - shift)
-        V.d_add_at(lin, n, -zh_zeta * blind[9] - w_mid * blind[10])
+        # ... and with them the constant and X^n corrections: PI(zeta), the sigma_3 / L1 constants, the quotient blinding, the
+        # opening values -- one launch for the five terms and the two coefficients
+        V.d_lincomb(lin, opening_terms,
+                    at=[(0, pi_zeta - alpha * f2 * (zc + gamma) - a2l1 + w_mid * blind[9] + w_hi * blind[10] - shift),
+                        (n, -zh_zeta * blind[9] - w_mid * blind[10])])
         quot, quot_w = DevVec(n + 5, zero=False), DevVec(n + 2, zero=False)
         assert V.d_div_linear(n + 6, lin.ptr(), zeta, quot.ptr()) == 0
         V.d_add_at(z, 0, -zzw)
