@@ -189,3 +189,33 @@ def test_relaxed_g2_step_host_build_and_integer_models(tmp_path):
     for model in ("model_relaxed_g2.py", "model_lazy_ntt.py"):
         res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", model)], capture_output=True, text=True, timeout=600)
         assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr
+
+
+def test_build_script_falls_back_to_plain_hipcc_when_the_pass_pipeline_cannot_be_reproduced(tmp_path):
+    """csrc/hipcc_noreassoc.sh drives clang / opt / llc by hand to leave LLVM's `reassociate` pass out of the device pipeline; on a
+    toolchain whose O3 pipeline text has no such pass it must not fail the build (round-3 advisor finding) but compile the unit
+    with the stock driver, LLCFLAGS travelling as -mllvm options.  Fake tools stand in for the toolchain."""
+    import stat
+    import subprocess
+    script = os.path.join(ROOT, "zksnake_amd", "csrc", "hipcc_noreassoc.sh")
+    llvm = tmp_path / "llvm"
+    llvm.mkdir()
+
+    def tool(path, body):
+        path.write_text("#!/bin/bash\n" + body)
+        path.chmod(path.stat().st_mode | stat.S_IXUSR)
+
+    tool(llvm / "clang++", 'while [ $# -gt 0 ]; do if [ "$1" = "-o" ]; then : > "$2"; fi; shift; done\n')
+    tool(llvm / "opt", 'echo "module(function(instcombine,simplifycfg)),BitcodeWriterPass"; exit 1\n')   # no reassociate in this pipeline
+    hipcc = tmp_path / "hipcc"
+    tool(hipcc, f'echo "$@" > {tmp_path}/hipcc_args; while [ $# -gt 0 ]; do if [ "$1" = "-o" ]; then echo obj > "$2"; fi; shift; done\n')
+    src = tmp_path / "unit.hip"
+    src.write_text("// nothing\n")
+    out = tmp_path / "unit.o"
+    env = dict(os.environ, LLVM_BIN=str(llvm), HIPCC=str(hipcc), ARCH="gfx950", LLCFLAGS="-amdgpu-sched-strategy=max-ilp", TMPDIR=str(tmp_path))
+    res = subprocess.run(["bash", script, str(out), str(src), "-O3", "-DZK_GROUP=Bn254G1"], env=env, capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0, res.stderr
+    assert "plain hipcc" in res.stderr
+    args = (tmp_path / "hipcc_args").read_text()
+    assert "--offload-arch=gfx950" in args and "-mllvm -amdgpu-sched-strategy=max-ilp" in args and "-DZK_GROUP=Bn254G1" in args
+    assert out.read_text() == "obj\n"
