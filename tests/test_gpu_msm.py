@@ -774,3 +774,31 @@ def test_slots_with_their_own_window_ranges_and_wide_windows(gpu, cid, grp):
     assert arr.plan(0, precompute=True, window_bits=20, concurrent=True) == whole and arr._plan_concurrent[whole] is True
     arr.release()
     assert not arr._plans and not arr._plan_layout
+
+
+def test_window_layouts_of_sharded_and_unsharded_plans(gpu):
+    """zk_msm_window_layout_ex tells a rank of the task-partitioned prover both layouts of an MSM before any plan exists: the
+    one zk_msm_plan_create_range takes (16 windows of 16 bits for fixed-base plans, which split evenly) and the one
+    zk_msm_plan_create takes (13 of 20 bits from 2^20 points on); zk_msm_window_layout is the former"""
+    def layout(cid, grp, n, flags, all_windows, bits=0):
+        c, nw = N._i(0), N._i(0)
+        N.check(gpu.zk_msm_window_layout_ex(cid, grp, n, flags, bits, all_windows, c, nw))
+        return c.value, nw.value
+    for cid, scalar_bits in ((0, 254), (1, 255)):
+        for grp in (1, 2):
+            assert layout(cid, grp, 1 << 20, N.MSM_PRECOMPUTE, 0) == (16, 16)
+            assert layout(cid, grp, 1 << 20, N.MSM_PRECOMPUTE, 1) == (20, (scalar_bits + 1 + 19) // 20)
+            assert layout(cid, grp, 1 << 19, N.MSM_PRECOMPUTE, 1) == (16, 16)        # below 2^20 points the wide windows do not pay
+            assert layout(cid, grp, 1 << 23, N.MSM_PRECOMPUTE, 0, bits=20) == (20, (scalar_bits + 1 + 19) // 20)   # explicit width: ranges too
+            c, nw = N._i(0), N._i(0)
+            N.check(gpu.zk_msm_window_layout(cid, grp, 1 << 20, N.MSM_PRECOMPUTE, 0, c, nw))
+            assert (c.value, nw.value) == layout(cid, grp, 1 << 20, N.MSM_PRECOMPUTE, 0)
+    # the layout a plan reports is the one the query promised
+    from zksnake_amd._algebra import PointArray
+    _, bases = oracle_bases(0, 1, 300, 77)
+    arr = PointArray(0, 1, bases)
+    c, nw = N._i(0), N._i(0)
+    N.check(gpu.zk_msm_plan_windows(arr.plan(0, precompute=True), c, nw))
+    assert (c.value, nw.value) == layout(0, 1, 300, N.MSM_PRECOMPUTE, 1)
+    arr.release()
+    assert gpu.zk_msm_window_layout_ex(2, 1, 100, 0, 0, 0, c, nw) == N.ZK_ERR_ARG

@@ -246,6 +246,45 @@ def test_qap_pipeline_matches_oracle(gpu, name, cid, n):
 
 
 @pytest.mark.parametrize("name,cid", CURVES)
+@pytest.mark.parametrize("n", [8, 4096, 1 << 13])
+def test_qap_uv_only_and_two_step_form(gpu, name, cid, n):
+    """zk_qap_uv_dev (what a rank of the task-partitioned prover runs when its MSM reads u or v only) gives the u and v of the
+    whole chain, for either vector alone as well; zk_qap_h_dev_begin / _end (the form prove() uses, with the fused passes of
+    round 4: coset shift on the inverse transforms' last pass, the quotient formed by the last transform's first pass) agree
+    with the one-call form and the oracle, in single-pass (n <= 2048) and multi-pass transforms"""
+    from zksnake_amd.device import DeviceBuffer
+    cv = pyref.curve_by_name(name)
+    A, B, C, n_row, n_col, n_pub, w = pyref.chain_circuit(n, cv.r)
+    a = N.ints_to_limbs(pyref.sparse_dot(A, n_row, w, cv.r))
+    b = N.ints_to_limbs(pyref.sparse_dot(B, n_row, w, cv.r))
+    c = N.ints_to_limbs(pyref.sparse_dot(C, n_row, w, cv.r))
+    eu, ev, eh = corc.qap_h(cid, a, b, c)
+    log_n = n.bit_length() - 1
+    da, db = DeviceBuffer.from_numpy(a), DeviceBuffer.from_numpy(b)
+    ev_ptr = N._vp()
+    N.check(gpu.zk_qap_uv_dev(cid, log_n, da.ptr, db.ptr, None, N.ctypes.byref(ev_ptr)))
+    gpu.zk_dev_synchronize()
+    assert ev_ptr.value and (da.download((n, 4)) == eu).all() and (db.download((n, 4)) == ev).all()
+    da.upload(a); db.upload(b)
+    N.check(gpu.zk_qap_uv_dev(cid, log_n, da.ptr, None, None, None))      # u alone, no event asked for
+    N.check(gpu.zk_qap_uv_dev(cid, log_n, None, db.ptr, None, None))      # v alone
+    gpu.zk_dev_synchronize()
+    assert (da.download((n, 4)) == eu).all() and (db.download((n, 4)) == ev).all()
+    # two-step form on a stream of its own; c must come through untouched (w is transformed straight out of it)
+    st = N._vp()
+    N.check(gpu.zk_stream_create(0, N.ctypes.byref(st)))
+    da.upload(a); db.upload(b)
+    dc, dh, dw = DeviceBuffer.from_numpy(c), DeviceBuffer(n * 32), DeviceBuffer(4 * n * 32)
+    N.check(gpu.zk_qap_h_dev_begin(cid, log_n, da.ptr, db.ptr, dc.ptr, dh.ptr, dw.ptr, st, N.ctypes.byref(ev_ptr)))
+    ok = N._i(0)
+    N.check(gpu.zk_qap_h_dev_end(cid, log_n, dw.ptr, ok, st))
+    assert ok.value == 1
+    assert (da.download((n, 4)) == eu).all() and (db.download((n, 4)) == ev).all() and (dh.download((n, 4)) == eh).all()
+    assert (dc.download((n, 4)) == c).all()
+    N.check(gpu.zk_stream_destroy(st))
+
+
+@pytest.mark.parametrize("name,cid", CURVES)
 def test_spmv(gpu, name, cid):
     from zksnake_amd.array import SparseArray
     from zksnake_amd.device import DeviceBuffer
