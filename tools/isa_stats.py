@@ -32,16 +32,10 @@ def main():
               f"ds {sum(c for o, c in ops.items() if o.startswith('ds_'))}  global {sum(c for o, c in ops.items() if o.startswith('global_'))}  "
               f"scratch {sum(c for o, c in ops.items() if o.startswith('scratch_'))}  s_waitcnt {ops.get('s_waitcnt', 0)}  s_nop {ops.get('s_nop', 0)}")
         print("  top:", ", ".join(f"{o} {c}" for o, c in ops.most_common(14)))
-        # register counts from the kernel's metadata note
-        mm = re.search(re.escape(name) + r"(.|\n)*?\.vgpr_count:\s+(\d+)", meta)
-        k = meta.find(name)
-        if k >= 0:
-            seg = meta[max(0, k - 1500):k + 1500]
-            for key in (".vgpr_count", ".sgpr_count", ".agpr_count", ".vgpr_spill_count", ".group_segment_fixed_size", ".private_segment_fixed_size"):
-                mk = re.search(re.escape(key) + r":\s+(\d+)", seg)
-                if mk:
-                    print(f"  {key[1:]} {mk.group(1)}", end="")
-            print()
+        # register counts from the kernel's metadata record (.name, .vgpr_count, .vgpr_spill_count appear in this order per kernel)
+        rec = re.search(r"\.name:\s+" + re.escape(name) + r"\s(?:.|\n)*?\.vgpr_count:\s+(\d+)\s*\n\s*\.vgpr_spill_count:\s+(\d+)", meta)
+        if rec:
+            print(f"  vgpr_count {rec.group(1)}  vgpr_spill_count {rec.group(2)}")
 
 
 if __name__ == "__main__":
