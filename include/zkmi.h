@@ -274,6 +274,9 @@ int zk_msm_plan_timings(uint64_t handle, float* ms, int cap);
  *   "priority_steps"    0 = the waves of the accumulate kernel keep one issue priority throughout   ZKMI_NO_PRIO_STEPS
  *                       (default 1: they step it down near the end of their segment, which keeps the waves of a SIMD together
  *                       when the kernel has the chip to itself; applies to zk_msm_plan_run / zk_msm_plan_enqueue only)
+ *   "split_pairs"       Fp2 groups: 1 = the accumulate kernel gives a segment to a lane PAIR and splits every   ZKMI_SPLIT_PAIRS
+ *                       Fp2 value by component over it (half the registers per lane), 0 = one lane per segment,
+ *                       -1 = the group's default (BLS12-381 G2: on, BN254 G2: off; measured, msm_accumulate.hip.h)
  * Results never depend on them.  ZK_ERR_ARG for unknown names (including the creation-time options ZKMI_SORT_WGS,
  * ZKMI_FINE_LOG, ZKMI_NO_GLV, ZKMI_PRE_C), for values the plan cannot honour and while a run is in flight. */
 int zk_msm_plan_set_option(uint64_t handle, const char* name, int64_t value);

@@ -802,3 +802,58 @@ def test_window_layouts_of_sharded_and_unsharded_plans(gpu):
     assert (c.value, nw.value) == layout(0, 1, 300, N.MSM_PRECOMPUTE, 1)
     arr.release()
     assert gpu.zk_msm_window_layout_ex(2, 1, 100, 0, 0, 0, c, nw) == N.ZK_ERR_ARG
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("flags", [0, N.MSM_PRECOMPUTE])
+def test_pair_split_g2_accumulate_kernel_equals_the_one_lane_kernel(gpu, cid, flags):
+    """the G2 accumulate step with every Fp2 value split by component over a lane pair (fp2_split.hip.h; default for BLS12-381 G2,
+    selectable for BN254 G2) against the one-lane kernel and the oracle: random scalars, and the cases that leave the main path --
+    the point at infinity as a base, P and -P in one bucket (cancellation), the same point twice with equal scalars (the doubling
+    branch), scalars 0 / 1 / r - 1, a bucket that receives one entry only"""
+    grp = 2
+    cv = pyref.BN254 if cid == 0 else pyref.BLS12_381
+    n = 2500
+    _, bases = oracle_bases(cid, grp, n, 51 + cid)
+    _, sc = rand_scalars(n, cv.r, 52 + cid)
+    PW = N.point_limbs(cid, grp)
+    # infinity, P / -P with equal scalars, duplicates with equal scalars, edge scalars
+    bases[5] = 0
+    neg = np.zeros(PW, dtype=np.uint64)
+    N.check(gpu.zk_point_neg(cid, grp, N.u64p(bases[10]), N.u64p(neg)))
+    bases[11] = neg
+    sc[11] = sc[10]
+    bases[21] = bases[20]
+    sc[21] = sc[20]
+    bases[31] = bases[30]
+    bases[32] = bases[30]
+    sc[31] = sc[30]
+    sc[32] = sc[30]
+    sc[40] = 0
+    sc[41] = N.ints_to_limbs([1])[0]
+    sc[42] = N.ints_to_limbs([cv.r - 1])[0]
+    exp = corc.msm(cid, grp, sc, bases, threads=8)
+    h = N._u64(0)
+    N.check(gpu.zk_msm_plan_create(cid, grp, n, bases.ctypes.data, 0, flags, 0, h))
+    outs = {}
+    for mode in (0, 1, -1):
+        N.check(gpu.zk_msm_plan_set_option(h, b"split_pairs", mode))
+        out = np.zeros(PW, dtype=np.uint64)
+        N.check(gpu.zk_msm_plan_run(h, n, sc.ctypes.data, 0, 0, 0, N.u64p(out), None))
+        outs[mode] = out
+        assert (out == exp).all(), f"split_pairs = {mode}"
+    # a short MSM: most buckets hold a single entry (the accumulator is replaced, never added to)
+    for mode in (0, 1):
+        N.check(gpu.zk_msm_plan_set_option(h, b"split_pairs", mode))
+        out = np.zeros(PW, dtype=np.uint64)
+        N.check(gpu.zk_msm_plan_run(h, 7, sc.ctypes.data, 0, 0, 0, N.u64p(out), None))
+        assert (out == corc.msm(cid, grp, sc[:7], bases[:7], threads=1)).all()
+    assert gpu.zk_msm_plan_set_option(h, b"split_pairs", 2) == N.ZK_ERR_ARG
+    N.check(gpu.zk_msm_plan_destroy(h))
+    # the base-field groups have no such kernel
+    _, b1 = oracle_bases(cid, 1, 16, 3)
+    h1 = N._u64(0)
+    N.check(gpu.zk_msm_plan_create(cid, 1, 16, b1.ctypes.data, 0, 0, 0, h1))
+    assert gpu.zk_msm_plan_set_option(h1, b"split_pairs", 1) == N.ZK_ERR_ARG
+    N.check(gpu.zk_msm_plan_set_option(h1, b"split_pairs", 0))
+    N.check(gpu.zk_msm_plan_destroy(h1))

@@ -13,7 +13,7 @@ SOURCES = {
     "msm": ("zksnake_amd/csrc/msm_impl.hip.h", "zksnake_amd/csrc/msm_accumulate.hip.h", "zksnake_amd/csrc/msm_common.hip.h",
             "zksnake_amd/csrc/msm_sort.hip.h", "zksnake_amd/csrc/msm_reduce.hip.h", "zksnake_amd/csrc/curve.hip.h",
             "zksnake_amd/csrc/field.hip.h", "zksnake_amd/csrc/field_params.h", "zksnake_amd/csrc/msm_plan.h",
-            "zksnake_amd/csrc/pair.hip.h", "zksnake_amd/csrc/hipcc_noreassoc.sh", "zksnake_amd/csrc/Makefile"),
+            "zksnake_amd/csrc/pair.hip.h", "zksnake_amd/csrc/fp2_split.hip.h", "zksnake_amd/csrc/hipcc_noreassoc.sh", "zksnake_amd/csrc/Makefile"),
 }
 SOURCES["prove"] = SOURCES["msm"] + ("zksnake_amd/csrc/ntt.hip", "zksnake_amd/csrc/fr_mem.hip.h", "zksnake_amd/groth16/protocol.py",
                                       "zksnake_amd/groth16/qap.py")

@@ -2,6 +2,14 @@
 // sorted entry list), and the conversion of the bases to Montgomery form.  Pipeline overview: msm_impl.hip.h.
 #pragma once
 #include "msm_common.hip.h"
+#include "fp2_split.hip.h"
+// waves per SIMD the pair-split G2 kernels are compiled for (the second launch-bound parameter); tuned by measurement
+#ifndef ZK_SPLIT_WAVES_BN
+#define ZK_SPLIT_WAVES_BN 3
+#endif
+#ifndef ZK_SPLIT_WAVES_BLS
+#define ZK_SPLIT_WAVES_BLS 1
+#endif
 
 namespace zkmi {
 
@@ -81,6 +89,91 @@ __global__ __launch_bounds__(256, AccumulateWaves<G>::PER_SIMD) void accumulate_
     }
     xyzz_relaxed_finish<F>(acc);
     store_xyzz<F>(run_slot<F>(partials, buckets, run_start, bucket_start, key, t, seg_len), acc);
+}
+
+// ---- 5'. the same kernel for the Fp2 groups with every value split over a LANE PAIR (fp2_split.hip.h): the even lane of a pair
+// holds the c0 components of the accumulator and of the base, the odd lane the c1 components; a pair owns one segment.  Half the
+// state per lane, the same products, the same results, 14 % more instructions in all (operand selects, exchanges, the sums and
+// differences both lanes form).  Measured at 2^20 pairs (tools/group_msm_bench.py, one box, accumulate kernel only):
+//   BLS12-381 G2   401 registers, ONE wave per SIMD: 7.98 ms   ->  split, 245 registers, two waves: 7.49-7.61 ms   (default ON)
+//                  (held to three waves: 8.00)
+//   BN254 G2       256 registers, two waves: 3.10 ms            ->  split at two / three / four waves: 3.35 / 3.27 / 3.48   (default OFF:
+//                  the one-lane kernel already runs two waves; a third does not buy back the extra instructions)
+// Plan option "split_pairs" (-1 = the group's default, 0, 1) or ZKMI_SPLIT_PAIRS=0/1 choose per plan.
+template <class G> struct AccumulateSplit { static constexpr bool ON = false; static constexpr bool DEFAULT = false; static constexpr int WAVES = 1; };
+template <> struct AccumulateSplit<Bn254G2> { static constexpr bool ON = true; static constexpr bool DEFAULT = false; static constexpr int WAVES = ZK_SPLIT_WAVES_BN; };
+template <> struct AccumulateSplit<Bls381G2> { static constexpr bool ON = true; static constexpr bool DEFAULT = true; static constexpr int WAVES = ZK_SPLIT_WAVES_BLS; };
+
+template <class P>
+__device__ __forceinline__ Fp<P> load_component(const uint32_t* p) {
+    uint32_t w[P::W];
+    load_words<P::W>(w, p);
+    return fp_load<P>(w);
+}
+// this lane's component of the four coordinates of an XYZZ row [X.c0 X.c1 | Y.c0 Y.c1 | ZZ.. | ZZZ..]
+template <class P>
+__device__ __forceinline__ void store_split_xyzz(uint32_t* row, bool odd, const SplitXYZZ<P>& a) {
+    constexpr int W = P::W;
+    uint32_t w[W];
+    uint32_t* base = row + (odd ? W : 0);
+    fp_store<P>(w, a.X);   store_words<W>(base, w);
+    fp_store<P>(w, a.Y);   store_words<W>(base + 2 * W, w);
+    fp_store<P>(w, a.ZZ);  store_words<W>(base + 4 * W, w);
+    fp_store<P>(w, a.ZZZ); store_words<W>(base + 6 * W, w);
+}
+
+template <class G>
+__global__ __launch_bounds__(256, AccumulateSplit<G>::WAVES) void accumulate_split_kernel(const uint32_t* __restrict__ bases,
+                                                         const uint32_t* __restrict__ sorted,
+                                                         const uint32_t* __restrict__ bucket_start,
+                                                         const uint32_t* __restrict__ run_start, uint32_t n_keys,
+                                                         uint32_t seg_len, uint32_t prio_steps, uint32_t* __restrict__ partials,
+                                                         uint32_t* __restrict__ buckets) {
+    typedef typename G::F F;
+    typedef typename F::Params P;
+    constexpr int W = P::W;        // words per component
+    constexpr int AW = 4 * W;      // affine row: x.c0 x.c1 y.c0 y.c1
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = gt >> 1;    // the pair's segment
+    const bool odd = (gt & 1) != 0;
+    const uint32_t total = bucket_start[n_keys];
+    const uint32_t begin = t * seg_len;
+    if (begin >= total) return;    // both lanes of a pair leave together
+    uint32_t end = begin + seg_len;
+    if (end > total) end = total;
+    uint32_t lo = 0, hi = n_keys;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (bucket_start[mid] <= begin) lo = mid; else hi = mid;
+    }
+    uint32_t key = lo;
+    uint32_t next = bucket_start[key + 1];
+    SplitXYZZ<P> acc = sp_inf<P>();
+    const uint32_t q1 = seg_len - seg_len / 4, q2 = seg_len - seg_len / 10, q3 = seg_len - (seg_len + 31) / 32;
+    if (prio_steps) __builtin_amdgcn_s_setprio(3);   // the priority steps of accumulate_kernel, see there
+    for (uint32_t e = begin; e < end; ++e) {
+        if (prio_steps) {
+            const uint32_t step = __builtin_amdgcn_readfirstlane(e - begin);
+            if (step == q1) __builtin_amdgcn_s_setprio(2);
+            else if (step == q2) __builtin_amdgcn_s_setprio(1);
+            else if (step == q3) __builtin_amdgcn_s_setprio(0);
+        }
+        if (e == next) {
+            acc.X = fp_reduce_2p<P>(acc.X);   // xyzz_relaxed_finish, by component
+            store_split_xyzz<P>(run_slot<F>(partials, buckets, run_start, bucket_start, key, t, seg_len), odd, acc);
+            acc = sp_inf<P>();
+            do {
+                ++key;
+                next = bucket_start[key + 1];
+            } while (next <= e);
+        }
+        const uint32_t ref = sorted[e];
+        const uint32_t* src = bases + (size_t)(ref & 0x7FFFFFFFu) * AW + (odd ? W : 0);
+        const Fp<P> qx = load_component<P>(src), qy = load_component<P>(src + 2 * W);
+        sp_add_affine<P>(acc, qx, qy, (ref >> 31) != 0, odd);
+    }
+    acc.X = fp_reduce_2p<P>(acc.X);
+    store_split_xyzz<P>(run_slot<F>(partials, buckets, run_start, bucket_start, key, t, seg_len), odd, acc);
 }
 
 // ---- bases: canonical -> Montgomery; batch scalar multiplication -------------------------------------

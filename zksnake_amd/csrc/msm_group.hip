@@ -19,8 +19,17 @@
 
 namespace zkmi {
 
+// the pair-split accumulate kernel exists for the Fp2 groups only (msm_accumulate.hip.h: AccumulateSplit)
+#define ZK_SPLIT_Bn254G1 0
+#define ZK_SPLIT_Bn254G2 1
+#define ZK_SPLIT_Bls381G1 0
+#define ZK_SPLIT_Bls381G2 1
+
 #if ZK_PART == 1
 template __global__ void accumulate_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t*);
+#if ZK_CAT(ZK_SPLIT_, ZK_GROUP)
+template __global__ void accumulate_split_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t*);
+#endif
 template __global__ void bases_to_mont_kernel<ZK_GROUP>(const uint32_t*, uint64_t, uint32_t*, int);
 #elif ZK_PART == 2
 template __global__ void combine_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*);

@@ -47,6 +47,7 @@ namespace zkmi {
 #if defined(ZK_GROUP) && (!defined(ZK_PART) || ZK_PART == 0)
 // the plan's translation unit does not instantiate the heavy kernels (see msm_group.hip)
 extern template __global__ void accumulate_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t*);
+extern template __global__ void accumulate_split_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t*);   // instantiated for the Fp2 groups (msm_group.hip)
 extern template __global__ void bases_to_mont_kernel<ZK_GROUP>(const uint32_t*, uint64_t, uint32_t*, int);
 extern template __global__ void combine_kernel<ZK_GROUP>(const uint32_t*, const uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*);
 extern template __global__ void strided_sum_kernel<ZK_GROUP>(const uint32_t*, uint32_t*, SumJob, SumJob, uint32_t);
@@ -503,7 +504,15 @@ struct MsmPlan : MsmPlanBase {
         Work& l = ws;
         const uint32_t n_keys = l.groups * B;
         const uint64_t lanes_needed = ((uint64_t)l.w_count * m + seg_len - 1) / seg_len;
-        hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((lanes_needed + 255) / 256)), dim3(256), 0, st, d_bases, p_sorted, p_bstart, p_sstart, n_keys, seg_len, prio_steps ? 1u : 0u, l.partials, l.buckets);
+        bool launched = false;
+        if constexpr (AccumulateSplit<G>::ON) {
+            if (opt.split_pairs < 0 ? AccumulateSplit<G>::DEFAULT : opt.split_pairs != 0) {
+                // Fp2 groups: a lane PAIR per segment, every value split by component (fp2_split.hip.h)
+                hipLaunchKernelGGL(accumulate_split_kernel<G>, dim3((unsigned)((2 * lanes_needed + 255) / 256)), dim3(256), 0, st, d_bases, p_sorted, p_bstart, p_sstart, n_keys, seg_len, prio_steps ? 1u : 0u, l.partials, l.buckets);
+                launched = true;
+            }
+        }
+        if (!launched) hipLaunchKernelGGL(accumulate_kernel<G>, dim3((unsigned)((lanes_needed + 255) / 256)), dim3(256), 0, st, d_bases, p_sorted, p_bstart, p_sstart, n_keys, seg_len, prio_steps ? 1u : 0u, l.partials, l.buckets);
         ZK_HIP(hipEventRecord(l.ev_acc1, st));
         const uint32_t small_blocks = (2 * n_keys + COMBINE_THREADS - 1) / COMBINE_THREADS;
         hipLaunchKernelGGL(combine_kernel<G>, dim3(small_blocks + COMBINE_WAVE_BLOCKS + COMBINE_BIG_BLOCKS), dim3(COMBINE_THREADS), 0, st,
@@ -600,6 +609,10 @@ struct MsmPlan : MsmPlanBase {
             opt.lanes_per_output = (uint32_t)value;
         } else if (!strcmp(name, "priority_steps")) {
             opt.priority_steps = value != 0;
+        } else if (!strcmp(name, "split_pairs")) {
+            if (value < -1 || value > 1) return fail(ZK_ERR_ARG, "split_pairs: -1 (the group's default), 0 or 1");
+            if (value == 1 && !AccumulateSplit<G>::ON) return fail(ZK_ERR_ARG, "split_pairs: this group has no pair-split accumulate kernel (base-field groups)");
+            opt.split_pairs = (int)value;
         } else if (!strcmp(name, "two_level_sort")) {
             if (value && !ws.tmp_ref) return fail(ZK_ERR_ARG, "the plan was created without the buffers of the two-level sort");
             if (!value && wide) return fail(ZK_ERR_ARG, "windows wider than 16 bits exist in the two-level sort only");

@@ -113,6 +113,8 @@ struct MsmOptions {
     bool two_level_sort = true;              // ZKMI_NO_TWO_LEVEL clears it: one-level / bucket-range sorts only (c <= 16)
     bool priority_steps = true;              // ZKMI_NO_PRIO_STEPS clears it: accumulate waves step their issue priority down near the
                                              // end of their segment (plain runs only, msm_accumulate.hip.h)
+    int split_pairs = -1;                    // ZKMI_SPLIT_PAIRS=0/1: the G2 accumulate kernel with a lane PAIR per segment and every Fp2 value
+                                             // split by component (fp2_split.hip.h); -1 = the group's default (BLS12-381 G2 on, BN254 G2 off)
     // layout (creation time only)
     uint32_t sort_workgroups = 256;          // ZKMI_SORT_WGS: bucket-range sort workgroups over all windows
     int fine_log = 0;                        // ZKMI_FINE_LOG: fine bucket bits of the two-level sort (0 = automatic)
@@ -125,6 +127,7 @@ struct MsmOptions {
         if (const char* e = getenv("ZKMI_LPO")) o.lanes_per_output = (uint32_t)atoi(e);
         o.two_level_sort = getenv("ZKMI_NO_TWO_LEVEL") == nullptr;
         o.priority_steps = getenv("ZKMI_NO_PRIO_STEPS") == nullptr;
+        if (const char* e = getenv("ZKMI_SPLIT_PAIRS")) o.split_pairs = atoi(e) != 0 ? 1 : 0;
         if (const char* e = getenv("ZKMI_SORT_WGS")) o.sort_workgroups = (uint32_t)atoi(e);
         if (const char* e = getenv("ZKMI_FINE_LOG")) o.fine_log = atoi(e);
         o.trace_init = getenv("ZKMI_TRACE_INIT") != nullptr;
@@ -135,7 +138,7 @@ struct MsmOptions {
 struct MsmPlanBase {
     virtual ~MsmPlanBase() {}
     MsmOptions opt = MsmOptions::from_env();
-    // name: "segment_lanes", "sum_one_step", "lanes_per_output", "two_level_sort", "priority_steps"; ZK_ERR_ARG for anything else, for a value
+    // name: "segment_lanes", "sum_one_step", "lanes_per_output", "two_level_sort", "priority_steps", "split_pairs"; ZK_ERR_ARG for anything else, for a value
     // the plan cannot honour (two-level sort without its buffers, one-level sort for windows wider than 16 bits) and while a
     // run is in flight
     virtual int set_option(const char* name, int64_t value) = 0;
