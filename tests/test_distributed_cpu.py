@@ -99,6 +99,10 @@ def test_partition_covers_every_window_once(curve_id, log_n):
         assert max(projected) <= ref_cost + 1e-9, (world, max(projected), ref_cost)
         assert all(sorted(w for mine in ref for t, (f, c) in mine.items() if t == task for w in range(f, f + c)) == list(range(nwin[task]))
                    for task in PROOF_TASKS)
+    # more ranks than (task, window) units: the surplus ranks hold nothing (they still take part in the proof's collective)
+    assignment, projected = partition_proof(100, {t: 16 for t in PROOF_TASKS}, 0, 1 << 12)
+    assert len(assignment) == 100 and sum(1 for mine in assignment if not mine) >= 20 and all(len(mine) <= 1 for mine in assignment)
+    assert sorted(w for mine in assignment for t, (f, c) in mine.items() if t == "v2" for w in range(f, f + c)) == list(range(16))
     # a circuit without private wires has no <kdelta_1, w> MSM
     assignment, _ = partition_proof(4, {"k": 0, "u": 16, "v1": 16, "v2": 16, "h": 16}, 0, 1 << 12)
     assert all("k" not in mine for mine in assignment)
