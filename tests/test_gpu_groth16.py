@@ -383,11 +383,12 @@ def test_bad_witness_fails_on_every_rank_of_a_sharded_prove(gpu):
     assert all(r[0] == exp and r[1] for r in results)
 
 
-@pytest.mark.parametrize("curve,world", [("BN254", 8), ("BLS12_381", 16)])
+@pytest.mark.parametrize("curve,world", [("BN254", 8), ("BLS12_381", 16), ("BN254", 40)])
 def test_simulated_ranks_of_the_task_partition(gpu, curve, world, monkeypatch):
     """the eight-rank partition of BASELINE configs[4] (and a sixteen-rank one) on ONE GPU in ONE process: every simulated rank
     runs its share of prove() up to the collective, the rows it would have contributed are collected, and a second pass hands
-    every rank the gathered matrix.  All ranks assemble the closed-form proof; every window is covered once."""
+    every rank the gathered matrix.  All ranks assemble the closed-form proof; every window is covered once.  Forty ranks at this
+    size leave most of them without any window."""
     from zksnake_amd import parallel
     cv = pyref.curve_by_name(curve)
     n = 1 << 10
@@ -429,8 +430,9 @@ def test_simulated_ranks_of_the_task_partition(gpu, curve, world, monkeypatch):
             covered.setdefault(task, []).extend(range(first, first + count))
     for task in ("k", "u", "v1", "v2", "h"):
         assert sorted(covered[task]) == list(range(len(covered[task]))), task
-    # with more ranks than MSMs most ranks hold ONE task, and few of them run the whole QAP chain
-    assert sum(len(g._my_tasks()) == 1 for g in provers) >= world - 4
+    # with more ranks than MSMs most ranks hold ONE task (or, with more ranks than the partition has pieces, nothing: such a rank
+    # uploads no witness and only contributes zeros to the collective), and few of them run the whole QAP chain
+    assert sum(len(g._my_tasks()) <= 1 for g in provers) >= world - 4
     assert sum("h" in g._qap_needs() for g in provers) < world   # not every rank runs the whole QAP chain
 
 

@@ -415,11 +415,17 @@ class Groth16:
         sharded = self._shard is not None and self._shard[1] > 1
         self._exchanged = not sharded
         try:
-            try:
-                res = self.qap.evaluate_witness_device(witness, after_upload=start_witness_msm, after_uv=start_uv_sorts if ordered else None,
-                                                       needs=self._qap_needs())
-            except ValueError as exc:
-                raise ValueError("Failed to evaluate with the given witness") from exc
+            if sharded and not self._my_tasks():
+                # more ranks than the partition has pieces: this rank holds no window of any MSM.  It uploads nothing and
+                # only takes part in the proof's collective (zero points, flag 0), then assembles the same proof as the others
+                from .qap import DeviceQapResult
+                res = DeviceQapResult(n_rows, None, None, None, None)
+            else:
+                try:
+                    res = self.qap.evaluate_witness_device(witness, after_upload=start_witness_msm, after_uv=start_uv_sorts if ordered else None,
+                                                           needs=self._qap_needs())
+                except ValueError as exc:
+                    raise ValueError("Failed to evaluate with the given witness") from exc
             return self._prove_msms(pk, res, early, ordered, r, s, q, t_start)
         except BaseException as exc:
             lib = N.load()
