@@ -31,6 +31,9 @@ def sum_points(curve_id, group, partials):
     return out
 
 
+_GATHER_BUFFERS = {}   # (world, words, device) -> (pinned host input, device input, device output, pinned host output)
+
+
 def all_gather_limbs(mine, device=None):
     """every rank contributes a flat uint64 vector of the same length; returns the (world, len) array.
     Uses the default torch.distributed process group (RCCL on GPUs, gloo on CPU)."""
@@ -38,16 +41,31 @@ def all_gather_limbs(mine, device=None):
     import torch.distributed as dist
 
     world = dist.get_world_size()
-    mine = torch.from_numpy(np.ascontiguousarray(mine, dtype=np.uint64).view(np.int64))
-    if device is not None:
-        mine = mine.to(device)
+    mine = np.ascontiguousarray(mine, dtype=np.uint64).reshape(-1)
+    words = mine.shape[0]
     # one flat collective (RCCL all-gather over xGMI; gloo on the CPU).  The output is the concatenation of the ranks'
     # vectors -- the form both backends accept -- and there is no fallback path: a failing collective surfaces as it is
     # (round-2 verdict: a retry with all_gather would have masked a genuine RCCL error on the first multi-GPU run)
-    flat = torch.zeros(world * mine.numel(), dtype=mine.dtype, device=mine.device)
-    dist.all_gather_into_tensor(flat, mine.reshape(-1))
-    gathered = flat.view((world,) + tuple(mine.shape))
-    return gathered.cpu().numpy().view(np.uint64)
+    if device is None:
+        src = torch.from_numpy(mine.view(np.int64))
+        flat = torch.empty(world * words, dtype=torch.int64)
+        dist.all_gather_into_tensor(flat, src)
+        return flat.view(world, words).numpy().view(np.uint64)
+    # On the GPU the payload is a few hundred bytes and the call sits on the critical path of every sharded MSM / proof: the
+    # staging tensors (page-locked on the host side) are kept per shape instead of being allocated per call
+    key = (world, words, str(device))
+    bufs = _GATHER_BUFFERS.get(key)
+    if bufs is None:
+        bufs = (torch.empty(words, dtype=torch.int64).pin_memory(), torch.empty(words, dtype=torch.int64, device=device),
+                torch.empty(world * words, dtype=torch.int64, device=device), torch.empty(world * words, dtype=torch.int64).pin_memory())
+        _GATHER_BUFFERS[key] = bufs
+    h_in, d_in, d_out, h_out = bufs
+    h_in.numpy()[:] = mine.view(np.int64)
+    d_in.copy_(h_in, non_blocking=True)
+    dist.all_gather_into_tensor(d_out, d_in)
+    h_out.copy_(d_out, non_blocking=True)
+    torch.cuda.current_stream(device).synchronize()
+    return h_out.view(world, words).numpy().view(np.uint64).copy()
 
 
 def all_gather_sum(curve_id, group, partial, device=None):
