@@ -150,9 +150,11 @@ int zk_spmv_long_dev(int curve, uint64_t n_long, const void* d_long_rows, const 
 /* Fused QAP.evaluate_witness tail (python/zksnake/groth16/qap.py:57-69): from the evaluation vectors
  * a = A.w, b = B.w, c = C.w (2^log_n canonical Fr elements each, device memory) compute in place the
  * coefficient vectors u = iNTT(a), v = iNTT(b) and write h (2^log_n elements, h[2^log_n - 1] = 0) with
- * u*v - w = h*(X^n - 1).  Everything stays in HBM.  The quotient is taken on the coset g*H of the n-point
- * domain, where X^n - 1 is the constant g^n - 1: 3 iNTT(n) + 3 NTT(n) of g^i-scaled coefficients + one point-wise pass +
- * 1 iNTT(n) and a g^-i scaling (the reference goes through the doubled domain: 2 NTT(2n) + iNTT(2n) + fold; same h).
+ * u*v - w = h*(X^n - 1).  Everything stays in HBM.  With u v = P_lo + X^n P_hi the quotient is h = P_hi, and on the coset g*H of the
+ * 2n-th root of unity g (g^n = -1) the values of u v interpolate P_lo - P_hi, so h = (w - d) / 2 with d = that interpolant: 3 iNTT(n)
+ * + 2 NTT(n) of g^i-scaled coefficients + 1 iNTT(n), the scalings and the point-wise product folded into the transforms' passes
+ * (the reference goes through the doubled domain: 2 NTT(2n) + iNTT(2n) + fold; same h).  log_n + 1 must not exceed the field's
+ * two-adicity (ZK_ERR_DOMAIN).
  * d_work must hold 4 * 2^log_n elements.  *divisible (host int) is set to 0 when a_i b_i != c_i for some i, i.e. when
  * the division would leave a remainder (the reference raises ValueError there); h is meaningless in that case. */
 int zk_qap_h_dev(int curve, int log_n, void* d_a_u, void* d_b_v, const void* d_c, void* d_h, void* d_work,

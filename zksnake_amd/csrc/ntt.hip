@@ -211,23 +211,24 @@ __global__ void twiddle9_kernel(uint32_t* out, Fp<P> zeta, uint32_t count) {
 // use_scale != 0: 1/N of the inverse transform); between two passes the elements travel as nine raw limb words with values
 // below 9p (in_raw / out_raw), see the range notes above.
 // What a pass can take on from the kernels around a transform (the QAP chain, qap_h_dev_impl):
-//   first pass   in_v / in_w != nullptr: the element is not read but FORMED, (in[p] * in_v[p] - in_w[p]) * z with z given as z R^2
-//                (the point-wise quotient of the coset evaluations; canonical inputs);
+//   first pass   in_v != nullptr: the element is not read but FORMED, in[p] * in_v[p] / R (the point-wise product of two coset
+//                evaluation vectors; canonical inputs);
 //   last pass    scale_tab != nullptr: the output is multiplied by scale_tab[index] (canonical Montgomery representatives, 8
-//                words: g^i / N or g^-i / N -- the coset shift rides on the product the inverse transform pays for 1/N anyway);
-//                with out2 != nullptr that goes to out2 and `out` still receives x * scale (u and u g^i from one pass).
+//                words: g^i / N, or a multiple of g^-i -- the coset shift rides on the product the inverse transform pays for 1/N
+//                anyway); with out2 != nullptr that goes to out2 and `out` still receives x * scale (u and u g^i from one pass);
+//                with add_tab != nullptr a second vector is added (h = w / 2 + d (-g^-i / 2N), see qap_h_dev_impl).
 struct NttFuse {
-    const uint32_t* in_v = nullptr;
-    const uint32_t* in_w = nullptr;
+    const uint32_t* in_v = nullptr;       // first pass: the element is not read but FORMED, mont(in[p], in_v[p]) = in[p] in_v[p] / R
     const uint32_t* scale_tab = nullptr;
     uint32_t* out2 = nullptr;
+    const uint32_t* add_tab = nullptr;    // last pass, with scale_tab and without out2: out = x * scale_tab[index] + add_tab[index]
 };
 
 template <class P>
 __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(const uint32_t* in, uint32_t* out,
                                                                const uint32_t* __restrict__ tw, int log_n,
                                                                int rem, int m, int q, int in_raw, int final_pass, Fp<P> scale, int use_scale,
-                                                               NttFuse fuse, Fp<P> zq) {
+                                                               NttFuse fuse) {
     constexpr int N = P::N;  // register limbs (LDS is limb-major)
     constexpr int W = P::W;  // words per canonical element in HBM
     constexpr int T = TW_WORDS;
@@ -257,12 +258,9 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(c
         if (in_raw) {
             x = load_limbs9<P>(in + (size_t)p * T);
         } else if (fuse.in_v) {
-            // (u v - w) z as Montgomery products of canonical integers: mont(u, v) = u v / R, mont(w, 1) = w / R, mont(., z R^2)
-            Fp<P> one = fp_zero<P>();
-            one.v[0] = 1;
-            const Fp<P> d = fp_sub<P>(fp_mul<P>(load_fr<P>(in + (size_t)p * W), load_fr<P>(fuse.in_v + (size_t)p * W)),
-                                      fp_mul<P>(load_fr<P>(fuse.in_w + (size_t)p * W), one));
-            x = fp_mul<P>(d, zq);   // < 2p, normalised
+            // the point-wise product of two canonical vectors, u v / R (the R travels with the linear transform and is undone by the
+            // last pass's table)
+            x = fp_mul<P>(load_fr<P>(in + (size_t)p * W), load_fr<P>(fuse.in_v + (size_t)p * W));   // < 2p, normalised
         } else {
             x = load_fr<P>(in + (size_t)p * W);
         }
@@ -371,6 +369,9 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_BLOCKS) void ntt_pass_kernel(c
                 if (fuse.out2) {
                     store_fr<P>(fuse.out2 + (size_t)po * W, fp_reduce_full<P>(fp_mul<P>(x, t)));
                     store_fr<P>(out + (size_t)po * W, fp_reduce_full<P>(fp_mul<P>(x, scale)));
+                } else if (fuse.add_tab) {
+                    const Fp<P> y = fp_add<P>(fp_mul<P>(x, t), load_fr<P>(fuse.add_tab + (size_t)po * W));   // < 2p + canonical -> below 2p
+                    store_fr<P>(out + (size_t)po * W, fp_reduce_full<P>(y));
                 } else {
                     store_fr<P>(out + (size_t)po * W, fp_reduce_full<P>(fp_mul<P>(x, t)));
                 }
@@ -641,7 +642,8 @@ struct NttPlanFuse {
     const uint32_t* src = nullptr;
     uint32_t* dst = nullptr;
     NttFuse k;
-    Fp<P> zq;
+    bool own_scale = false;   // an inverse transform multiplies by `scale` (canonical Montgomery form) instead of 1/N
+    Fp<P> scale;
 };
 
 template <class P>
@@ -664,6 +666,7 @@ static int ntt_dev_impl(int curve, int inverse, int log_n, uint32_t* d, hipStrea
         uint32_t nn[P::W] = {0};
         nn[0] = 1u << log_n;
         scale = fp_reduce_full<P>(fp_inv<P>(fp_from_canonical<P>(nn)));   // canonical: the last pass multiplies values < 9p by it
+        if (fuse && fuse->own_scale) scale = fuse->scale;
     }
     const int passes = log_n <= NTT_TILE_LOG ? 1 : (log_n + NTT_MAX_DIGIT - 1) / NTT_MAX_DIGIT;
     uint32_t* scratch = nullptr;
@@ -702,10 +705,10 @@ static int ntt_dev_impl(int curve, int inverse, int log_n, uint32_t* d, hipStrea
         const uint32_t tile = 1u << (m + q);
         const size_t lds_bytes = (size_t)P::N * (tile + 32) * 4;
         NttFuse kf;
-        if (fuse && i == 0) { kf.in_v = fuse->k.in_v; kf.in_w = fuse->k.in_w; }
-        if (fuse && last) { kf.scale_tab = fuse->k.scale_tab; kf.out2 = fuse->k.out2; }
+        if (fuse && i == 0) kf.in_v = fuse->k.in_v;
+        if (fuse && last) { kf.scale_tab = fuse->k.scale_tab; kf.out2 = fuse->k.out2; kf.add_tab = fuse->k.add_tab; }
         hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3(1u << (rest_bits - q)), dim3(NTT_THREADS), lds_bytes, stream, src, dst, tw, log_n, rem, m, q,
-                           i > 0 ? 1 : 0, last ? 1 : 0, scale, (last && inverse) ? 1 : 0, kf, fuse ? fuse->zq : fp_zero<P>());
+                           i > 0 ? 1 : 0, last ? 1 : 0, scale, (last && inverse) ? 1 : 0, kf);
         src = dst;
         which ^= 1;
         rem -= m;
@@ -815,105 +818,60 @@ static int div_vanishing_host_impl(uint64_t n, uint64_t len, const uint64_t* coe
 
 // ---- QAP quotient on a coset ------------------------------------------------------------------------------------
 // h = (u v - w) / (X^n - 1).  The reference multiplies u and v over the doubled domain and divides the 2n coefficients
-// (qap.py:51-67 -> mul_over_fft, divide_by_vanishing_poly).  The same polynomial costs less on a coset g H of the
-// n-point domain, where X^n - 1 is the CONSTANT g^n - 1: evaluate u, v, w there (three size-n transforms of the
-// coefficients scaled by g^i), form (u v - w) / (g^n - 1) point-wise and interpolate back (one inverse transform and a
-// scaling by g^-i): seven size-n transforms instead of three of size n and three of size 2n.  The quotient is exact iff
-// a_i b_i = c_i on the domain itself, which is checked directly on the evaluation vectors (the reference's "remainder
-// must be zero", qap.py:68-69).  g = the field's multiplicative generator (5 for BN254 Fr, 7 for BLS12-381 Fr).
-constexpr int COSET_SPLIT = 14;  // g^i = glo[i mod 2^14] * ghi[i >> 14]: two 512 KiB tables serve every size
-
-struct CosetTables {
-    uint32_t *lo = nullptr, *hi = nullptr, *lo_inv = nullptr, *hi_inv = nullptr;
+// (qap.py:51-67 -> mul_over_fft, divide_by_vanishing_poly).  Write u v = P_lo + X^n P_hi (both parts of degree < n): modulo X^n - 1
+// that is w = P_lo + P_hi, and the quotient is h = P_hi.  On the coset g H with g = the primitive 2n-th root of unity (g^n = -1)
+// the n values u(g w^i) v(g w^i) interpolate u v mod (X^n + 1) = P_lo - P_hi =: d, so
+//                                  h = (w - d) / 2
+// -- SIX size-n transforms (round 4; seven until then, on the coset 5 H with a point-wise division by the constant g^n - 1): the
+// three inverse transforms of a, b, c, two forward transforms of the g^i-shifted u and v, and one inverse transform of their
+// point-wise product.  And nothing between them (NttFuse): the shift g^i rides on the 1/N product of the inverse transforms'
+// last pass (u and v leave it twice: plain, for their MSMs, and shifted), w is read from c and written as w / 2, the product
+// u v is formed by the FIRST pass of the last inverse transform as it loads, and its LAST pass multiplies by -g^-i / (2N) and adds
+// w / 2: it writes h.  The quotient is exact iff a_i b_i = c_i on the domain itself, which is checked directly on the evaluation
+// vectors (the reference's "remainder must be zero", qap.py:68-69).
+struct QapTabs {
+    uint32_t *fwd = nullptr, *inv = nullptr;   // g^i / N and -g^-i R / (2N) as canonical Montgomery representatives, g = w_2n
 };
-static std::map<int, CosetTables> g_coset;  // per curve (under g_tw_mutex)
-static void free_coset_scale_tabs();
+static std::map<std::pair<int, int>, QapTabs> g_qap_tabs;   // (curve, log_n), under g_tw_mutex
 static void free_coset_tables() {  // caller holds g_tw_mutex
-    for (auto& kv : g_coset)
-        for (uint32_t* p : {kv.second.lo, kv.second.hi, kv.second.lo_inv, kv.second.hi_inv}) (void)hipFree(p);
-    g_coset.clear();
-    free_coset_scale_tabs();
+    for (auto& kv : g_qap_tabs) { (void)hipFree(kv.second.fwd); (void)hipFree(kv.second.inv); }
+    g_qap_tabs.clear();
 }
 
+// row log_n of the stage-major twiddle tables holds w_2n^(+-i), i < n, as nine-word Montgomery representatives
 template <class P>
-static Fp<P> coset_generator() {
-    uint32_t g[P::W] = {0};
-    g[0] = P::TWO_ADICITY == 28 ? 5u : 7u;  // BN254 Fr: 5 (two-adicity 28); BLS12-381 Fr: 7 (two-adicity 32)
-    return fp_from_canonical<P>(g);
-}
-
-template <class P>
-static int get_coset_tables(int curve, CosetTables* out, hipStream_t stream) {
-    std::lock_guard<std::mutex> lock(g_tw_mutex);
-    auto it = g_coset.find(curve);
-    if (it != g_coset.end()) { *out = it->second; return ZK_OK; }
-    CosetTables t;
-    const uint32_t cnt = 1u << COSET_SPLIT;
-    const size_t bytes = (size_t)cnt * P::W * 4;
-    for (uint32_t** p : {&t.lo, &t.hi, &t.lo_inv, &t.hi_inv}) ZK_HIP(hipMalloc(p, bytes));
-    Fp<P> g = coset_generator<P>(), gi = fp_inv<P>(g);
-    Fp<P> gs = g, gis = gi;
-    for (int k = 0; k < COSET_SPLIT; ++k) { gs = fp_sqr<P>(gs); gis = fp_sqr<P>(gis); }
-    hipLaunchKernelGGL(twiddle_kernel<P>, dim3(cnt / 256), dim3(256), 0, stream, t.lo, g, cnt);
-    hipLaunchKernelGGL(twiddle_kernel<P>, dim3(cnt / 256), dim3(256), 0, stream, t.hi, gs, cnt);
-    hipLaunchKernelGGL(twiddle_kernel<P>, dim3(cnt / 256), dim3(256), 0, stream, t.lo_inv, gi, cnt);
-    hipLaunchKernelGGL(twiddle_kernel<P>, dim3(cnt / 256), dim3(256), 0, stream, t.hi_inv, gis, cnt);
-    ZK_HIP(hipGetLastError());
-    ZK_HIP(hipStreamSynchronize(stream));
-    g_coset[curve] = t;
-    *out = t;
-    return ZK_OK;
-}
-
-// tab[i] = g^(+-i) / N as canonical Montgomery representatives (8 words): what the last pass of an inverse transform multiplies
-// by when the coset shift is folded into it (NttFuse::scale_tab)
-template <class P>
-__global__ void coset_scale_tab_kernel(uint32_t* __restrict__ tab, uint64_t n, const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi,
-                                       Fp<P> inv_n) {
+__global__ void qap_tabs_kernel(uint32_t* __restrict__ fwd, uint32_t* __restrict__ inv, uint64_t n, const uint32_t* __restrict__ row_f,
+                                const uint32_t* __restrict__ row_i, Fp<P> inv_n, Fp<P> c_inv) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fp<P> t = fp_mul<P>(load_fr<P>(lo + (size_t)(i & ((1u << COSET_SPLIT) - 1)) * P::W), load_fr<P>(hi + (size_t)(i >> COSET_SPLIT) * P::W));
-    t = fp_mul<P>(t, inv_n);   // (g^i R)(R/N)/R
-    store_fr<P>(tab + i * P::W, fp_reduce_full<P>(t));
+    store_fr<P>(fwd + i * P::W, fp_reduce_full<P>(fp_mul<P>(load_limbs9<P>(row_f + i * TW_WORDS), inv_n)));   // (g^i R)(R / N) / R
+    store_fr<P>(inv + i * P::W, fp_reduce_full<P>(fp_mul<P>(load_limbs9<P>(row_i + i * TW_WORDS), c_inv)));   // (g^-i R)(-R^2 / 2N) / R
 }
 
-struct CosetScaleTabs {
-    uint32_t *fwd = nullptr, *inv = nullptr;   // g^i / N, g^-i / N
-};
-static std::map<std::pair<int, int>, CosetScaleTabs> g_coset_scale;   // (curve, log_n), under g_tw_mutex
-
 template <class P>
-static int get_coset_scale_tabs(int curve, int log_n, const CosetTables& ct, CosetScaleTabs* out, hipStream_t stream) {
+static int get_qap_tabs(int curve, int log_n, QapTabs* out, hipStream_t stream) {
+    TwiddleSet ts;
+    int rc = get_twiddles<P>(curve, log_n + 1, &ts, stream);   // takes g_tw_mutex itself
+    if (rc) return rc;
     std::lock_guard<std::mutex> lock(g_tw_mutex);
-    auto it = g_coset_scale.find({curve, log_n});
-    if (it != g_coset_scale.end()) { *out = it->second; return ZK_OK; }
+    auto it = g_qap_tabs.find({curve, log_n});
+    if (it != g_qap_tabs.end()) { *out = it->second; return ZK_OK; }
     const uint64_t n = 1ull << log_n;
-    CosetScaleTabs t;
+    QapTabs t;
     ZK_HIP(hipMalloc(&t.fwd, n * P::W * 4));
     ZK_HIP(hipMalloc(&t.inv, n * P::W * 4));
     uint32_t nn[P::W] = {0};
-    nn[0] = (uint32_t)n;   // log_n <= 30 (ntt_dev_impl refuses more)
-    const Fp<P> inv_n = fp_inv<P>(fp_from_canonical<P>(nn));   // Montgomery form of 1/N
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(coset_scale_tab_kernel<P>, dim3(blocks), dim3(256), 0, stream, t.fwd, n, ct.lo, ct.hi, inv_n);
-    hipLaunchKernelGGL(coset_scale_tab_kernel<P>, dim3(blocks), dim3(256), 0, stream, t.inv, n, ct.lo_inv, ct.hi_inv, inv_n);
+    nn[0] = (uint32_t)n;
+    const Fp<P> inv_n = fp_inv<P>(fp_from_canonical<P>(nn));                            // R / N
+    const Fp<P> half = fp_inv<P>(fp_add<P>(fp_one<P>(), fp_one<P>()));                  // R / 2
+    const Fp<P> c_inv = fp_mul<P>(fp_neg<P>(fp_mul<P>(inv_n, half)), fp_const<P>(P::R2));   // -(R / 2N) R^2 / R = -R^2 / (2N)
+    const size_t row = (((size_t)1 << log_n) - 1) * TW_WORDS;
+    hipLaunchKernelGGL(qap_tabs_kernel<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t.fwd, t.inv, n, ts.fwd + row, ts.inv + row, inv_n, c_inv);
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipStreamSynchronize(stream));
-    g_coset_scale[{curve, log_n}] = t;
+    g_qap_tabs[{curve, log_n}] = t;
     *out = t;
     return ZK_OK;
-}
-
-// out[i] = in[i] * g^(+-i) (canonical in and out; the tables hold Montgomery forms, so two products leave x * g^i)
-template <class P>
-__global__ void coset_mul_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
-                                 const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fp<P> x = load_fr<P>(in + i * P::W);
-    x = fp_mul<P>(x, load_fr<P>(lo + (size_t)(i & ((1u << COSET_SPLIT) - 1)) * P::W));
-    x = fp_mul<P>(x, load_fr<P>(hi + (size_t)(i >> COSET_SPLIT) * P::W));
-    store_fr<P>(out + i * P::W, fp_reduce_full<P>(x));
 }
 
 // flag |= (a[i] * b[i] != c[i]) on the domain: the witness satisfies the constraints iff this never fires
@@ -927,23 +885,6 @@ __global__ void qap_eval_check_kernel(uint64_t n, const uint32_t* __restrict__ a
     one.v[0] = 1;
     Fp<P> r = fp_sub<P>(fp_mul<P>(load_fr<P>(a + i * P::W), load_fr<P>(b + i * P::W)), fp_mul<P>(load_fr<P>(c + i * P::W), one));
     if (!fp_is_zero<P>(r)) atomicOr(nonzero, 1);
-}
-
-// out[i] = (u[i] v[i] - w[i]) * z, z given as z R^2 (so that mont(mont(u, v) - mont(w, 1), z R^2) = (u v - w) z)
-template <class P>
-__global__ void qap_quotient_kernel(uint64_t n, const uint32_t* __restrict__ u, const uint32_t* __restrict__ v,
-                                    const uint32_t* __restrict__ w, Fp<P> z_r2, uint32_t* __restrict__ out) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fp<P> one = fp_zero<P>();
-    one.v[0] = 1;
-    Fp<P> d = fp_sub<P>(fp_mul<P>(load_fr<P>(u + i * P::W), load_fr<P>(v + i * P::W)), fp_mul<P>(load_fr<P>(w + i * P::W), one));
-    store_fr<P>(out + i * P::W, fp_reduce_full<P>(fp_mul<P>(d, z_r2)));
-}
-
-static void free_coset_scale_tabs() {  // caller holds g_tw_mutex
-    for (auto& kv : g_coset_scale) { (void)hipFree(kv.second.fwd); (void)hipFree(kv.second.inv); }
-    g_coset_scale.clear();
 }
 
 static std::mutex g_uv_mutex;
@@ -970,50 +911,44 @@ static void free_uv_events() {
 template <class P>
 static int qap_h_dev_impl(int curve, int log_n, uint32_t* a_u, uint32_t* b_v, const uint32_t* c, uint32_t* h,
                           uint32_t* work, int* divisible, hipStream_t stream, hipEvent_t uv_ready = nullptr) {
-    if (log_n > P::TWO_ADICITY) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
+    // the coset generator is the primitive 2n-th root of unity: one level of two-adicity above the domain
+    if (log_n + 1 > P::TWO_ADICITY || log_n > 30) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
     const uint64_t n = 1ull << log_n;
-
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    uint32_t* W0 = work;                     // w coefficients, then w on the coset
-    uint32_t* U1 = work + n * P::W;          // u on the coset, then the quotient's coset values
-    uint32_t* V1 = work + 2 * n * P::W;      // v on the coset
+    uint32_t* W0 = work;                     // w / 2 (coefficients)
+    uint32_t* U1 = work + n * P::W;          // u g^i, then u on the coset
+    uint32_t* V1 = work + 2 * n * P::W;      // v g^i, then v on the coset
     int* dflag = reinterpret_cast<int*>(work + 3 * n * P::W);
-    CosetTables ct;
+    QapTabs qt;
     int rc;
-    if ((rc = get_coset_tables<P>(curve, &ct, stream))) return rc;
-    CosetScaleTabs st;
-    if (log_n > 30) return fail(ZK_ERR_DOMAIN, "Domain size is too large");
-    if ((rc = get_coset_scale_tabs<P>(curve, log_n, ct, &st, stream))) return rc;
+    if ((rc = get_qap_tabs<P>(curve, log_n, &qt, stream))) return rc;
     ZK_HIP(hipMemsetAsync(dflag, 0, sizeof(int), stream));
     hipLaunchKernelGGL(qap_eval_check_kernel<P>, dim3(blocks), dim3(256), 0, stream, n, a_u, b_v, c, dflag);
-    // Seven transforms and nothing between them (round 4): the coset shift g^i rides on the 1/N product of the inverse
-    // transforms' last pass (u and v leave it twice: plain, for their MSMs, and shifted), w is read from c and written shifted,
-    // the point-wise quotient is formed by the first pass of the last inverse transform as it loads, and that transform's last
-    // pass multiplies by g^-i / N and writes h.  Before: four coset_mul launches, one quotient launch and a copy of c.
     NttPlanFuse<P> f;
-    f.k.scale_tab = st.fwd;
+    f.k.scale_tab = qt.fwd;
     f.k.out2 = U1;
     if ((rc = ntt_dev_impl<P>(curve, 1, log_n, a_u, stream, &f))) return rc;  // u, and u g^i into U1
     f.k.out2 = V1;
     if ((rc = ntt_dev_impl<P>(curve, 1, log_n, b_v, stream, &f))) return rc;  // v, and v g^i into V1
     if (uv_ready) ZK_HIP(hipEventRecord(uv_ready, stream));
-    f.k.out2 = nullptr;
-    f.src = c;
-    if ((rc = ntt_dev_impl<P>(curve, 1, log_n, W0, stream, &f))) return rc;   // w g^i, straight from c
-    if ((rc = ntt_dev_impl<P>(curve, 0, log_n, U1, stream))) return rc;
-    if ((rc = ntt_dev_impl<P>(curve, 0, log_n, V1, stream))) return rc;
-    if ((rc = ntt_dev_impl<P>(curve, 0, log_n, W0, stream))) return rc;
-    // 1 / (g^n - 1), carried as z R^2
-    Fp<P> gn = coset_generator<P>();
-    for (int k = 0; k < log_n; ++k) gn = fp_sqr<P>(gn);
-    Fp<P> z = fp_inv<P>(fp_sub<P>(gn, fp_one<P>()));          // Montgomery form: z R
-    NttPlanFuse<P> fq;
-    fq.zq = fp_mul<P>(z, fp_const<P>(P::R2));                 // z R * R^2 / R = z R^2
+    NttPlanFuse<P> fw;   // w / 2 straight from c: the inverse transform's scale is 1 / (2N)
+    fw.src = c;
+    fw.own_scale = true;
+    {
+        uint32_t nn[P::W] = {0};
+        nn[0] = (uint32_t)n;
+        const Fp<P> two_n = fp_add<P>(fp_from_canonical<P>(nn), fp_from_canonical<P>(nn));
+        fw.scale = fp_reduce_full<P>(fp_inv<P>(two_n));
+    }
+    if ((rc = ntt_dev_impl<P>(curve, 1, log_n, W0, stream, &fw))) return rc;
+    if ((rc = ntt_dev_impl<P>(curve, 0, log_n, U1, stream))) return rc;       // u on g H
+    if ((rc = ntt_dev_impl<P>(curve, 0, log_n, V1, stream))) return rc;       // v on g H
+    NttPlanFuse<P> fq;   // h = w / 2 + iNTT_unscaled(u v / R) * (-g^-i R / 2N)
     fq.k.in_v = V1;
-    fq.k.in_w = W0;
-    fq.k.scale_tab = st.inv;
+    fq.k.scale_tab = qt.inv;
+    fq.k.add_tab = W0;
     fq.dst = h;
-    if ((rc = ntt_dev_impl<P>(curve, 1, log_n, U1, stream, &fq))) return rc;  // h = iNTT((u v - w) z) g^-i
+    if ((rc = ntt_dev_impl<P>(curve, 1, log_n, U1, stream, &fq))) return rc;
     ZK_HIP(hipGetLastError());
     if (!divisible) return ZK_OK;
     int flag = 0;
