@@ -497,7 +497,7 @@ class Groth16:
             B2 = msm_v2 + b2_fixed
             C = HZ + sum_delta_witness + A * s + B1 * r + c_fixed
         t_end = time.perf_counter()
-        # qap_ms is the part a window-sharded prover REPLICATES on every rank (witness upload, three sparse products, seven
+        # qap_ms is the part a window-sharded prover REPLICATES on every rank (witness upload, three sparse products, six
         # transforms); msm_* is what the ranks share; collective_ms the all_gather of the partial points inside the exchange
         self.last_timings = {"qap_ms": (t_qap - t_start) * 1e3, "msm_enqueue_ms": (t_enq - t_qap) * 1e3,
                              "msm_finish_ms": (t_fin - t_enq) * 1e3, "exchange_assemble_ms": (t_end - t_fin) * 1e3,

@@ -94,8 +94,8 @@ _MSM_COST_MS = {
     (0, 1): (0.086, 0.38, 0.20), (0, 2): (0.225, 0.50, 0.35),
     (1, 1): (0.170, 0.50, 0.30), (1, 2): (0.590, 0.90, 0.60),
 }
-# witness upload, one sparse product + one inverse transform, the whole chain (three products, seven transforms)
-_QAP_COST_MS = {"upload": 0.60, "u": 0.20, "v": 0.20, "h": 1.20}
+# witness upload, one sparse product + one inverse transform, the whole chain (three products, six transforms)
+_QAP_COST_MS = {"upload": 0.60, "u": 0.20, "v": 0.20, "h": 1.05}
 
 PROOF_TASKS = ("k", "u", "v1", "v2", "h")           # line order
 TASK_NEEDS = {"k": "w", "u": "u", "v1": "v", "v2": "v", "h": "h"}
