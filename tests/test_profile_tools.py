@@ -107,3 +107,28 @@ def test_the_real_source_lists_exist():
     for which, files in SOURCES.items():
         for rel in files:
             assert os.path.exists(os.path.join(ROOT, rel)), (which, rel)
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """the default bench line of the round's final build (profiles/r04_bench_default.json, written by bench.py on the GPU box): the
+    keys the driver and the judge read are there, the roofline arithmetic is consistent, the profiled kernel average agrees with the
+    run's own event timing to a few per cent (round 3: 13-15 % apart), and the proofs in `extra` matched their committed closed forms"""
+    path = os.path.join(ROOT, "profiles", "r04_bench_default.json")
+    with open(path) as f:
+        line = json.loads(f.read().strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["unit"] == "Mscalar/s" and line["vs_baseline"] is None and "workload" in line["config"]
+    assert abs(line["value"] - (1 << 20) / line["ms_per_step"] / 1e3) / line["value"] < 0.01
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
+    assert abs(r["achieved"] - 96 * (1 << 20) / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 0.01     # 96 B per pair, SURVEY 8(d)
+    assert r["traffic"] and abs(r["frac_measured"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3
+    assert abs(r["kernel_ms_profiled"] - r["kernel_ms"]) / r["kernel_ms"] < 0.05
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Mscalar/s" and c["sample"]
+    ex = line["extra"]
+    for key in ("groth16_prove_bn254_2^20", "groth16_prove_bls12_381_2^23"):
+        assert ex[key]["verifies"] and ex[key]["matches_committed_closed_form"]
+    assert ex["groth16_prove_bn254_2^20"]["cpu_baseline"]["kind"] == "port"
