@@ -36,6 +36,11 @@ for burst in range(2):
         N.check(lib.zk_msm_plan_run(h, n, d.ptr, 1, 0, 0, N.u64p(out), None))
         wall = (time.perf_counter() - t0) * 1e3
         lib.zk_msm_plan_timings(h, tm, 5)
-        rows.append((step, wall, tm[1]))
+        rows.append((step, wall, tm[1], tm[0], tm[2], tm[3]))
     marks = [1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 300]
     print(f"burst {burst} after {idle} s idle:", "  ".join(f"#{s}: {rows[s - 1][1]:.3f}/{rows[s - 1][2]:.3f}" for s in marks))
+    if burst == 1:
+        print("steady state, steps 200-223 (wall / sort / accumulate / reduce / tail):")
+        for s in range(200, 224):
+            r = rows[s - 1]
+            print(f"  #{s}: {r[1]:.3f}  {r[3]:.3f} {r[2]:.3f} {r[4]:.3f} {r[5]:.3f}")
