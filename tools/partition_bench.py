@@ -63,7 +63,7 @@ def run(curve, log_n, world, partition, reps):
         lib = N.load()
         for rank, (g, setup_s) in enumerate(provers):
             state["rank"] = rank
-            times, tls = [], []
+            times, qaps = [], []
             for _ in range(reps + 1):
                 lib.zk_dev_synchronize()
                 t0 = time.perf_counter()
@@ -72,9 +72,12 @@ def run(curve, log_n, world, partition, reps):
                 except _Stop:
                     pass
                 times.append((state["t_stop"] - t0) * 1e3)
+                qaps.append(g.last_timings.get("qap_ms", 0.0))
             mine = g._my_tasks()
             per_rank.append({"rank": rank, "tasks": {t: list(v) for t, v in mine.items()}, "qap_outputs": sorted(g._qap_needs()),
                              "ms_to_collective": round(statistics.median(times[1:]), 3), "ms_min": round(min(times[1:]), 3),
+                             "upload_and_qap_ms": round(statistics.median(qaps[1:]), 3),
+                             "msm_phase_ms": round(statistics.median(times[1:]) - statistics.median(qaps[1:]), 3),
                              "projected_ms": g.projected_ms[rank] if g.projected_ms else None, "setup_s": round(setup_s, 2)})
         state["gathered"] = np.stack([rows[k] for k in range(world)])
         for rank, (g, _) in enumerate(provers):
@@ -87,6 +90,7 @@ def run(curve, log_n, world, partition, reps):
         gc.unfreeze()
     out = {"curve": curve, "log_n": log_n, "world": world, "partition": partition,
            "slowest_rank_ms": max(p["ms_to_collective"] for p in per_rank),
+           "slowest_msm_phase_ms": max(p["msm_phase_ms"] for p in per_rank),
            "sum_over_ranks_ms": round(sum(p["ms_to_collective"] for p in per_rank), 3),
            "all_ranks_same_proof": same, "verifies": verifies, "per_rank": per_rank}
     gpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "groth16_vectors.json")

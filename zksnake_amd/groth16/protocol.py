@@ -442,6 +442,7 @@ class Groth16:
     def _prove_msms(self, pk, res, early, ordered, r, s, q, t_start):
         import time
         t_qap = time.perf_counter()
+        self.last_timings = {"qap_ms": (t_qap - t_start) * 1e3}   # completed below; a sharded rank that stops at the collective keeps this
         self._collective_ms = 0.0
         n = res.n
         # The four MSMs over u, v, h run on their plans' own streams.  An accumulate kernel fills every wave slot of the
